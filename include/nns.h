@@ -1,0 +1,173 @@
+/*
+ * nns.h — C ABI of the MI355X-native brute-force nearest-neighbour engine.
+ *
+ * This is the drop-in boundary for the reference's "distance matrix + argmin"
+ * path (sty-hhh/NNS-CUDA, V0-V9).  Every entry point is plain C: pointers and
+ * sizes, no C++/torch types.  The shared library is libnns_mi355x.so
+ * (nns-cuda_amd/csrc, hand-written HIP for gfx950).
+ *
+ * Reference interface replaced (file:line are into the reference tree):
+ *   - vN::cudaCall(int k, int m, int n, float *s_points, float *r_points,
+ *                  int **results)                     core.cu:23-29 (V0) and the
+ *     identical signatures at core.cu:123, 177, 258, 350, 427, 538, 634, 761,
+ *     965; selected through the function pointer of main.cu:7, called at
+ *     main.cu:74.                                  -> nns_search_f32()
+ *   - the per-GPU shard body of V8/V9 (core.cu:778-829, 982-1033): upload a
+ *     contiguous ref shard, transpose (mat_inv_kernel core.cu:293-306), run the
+ *     fused distance+argmin kernel.                -> nns_index_create() +
+ *                                                     nns_index_search()
+ *   - the V7/V8/V9 second-stage merge (core.cu:675-696, 832-852, 1036-1056).
+ *                                                  -> nns_keys_min() /
+ *                                                     an RCCL min all-reduce on
+ *                                                     the packed keys.
+ *   - utils.h CHECK (print + exit(1), utils.h:16-26): the C ABI never exits; it
+ *     returns a status code (the C++ shim mi355x::cudaCall reproduces the
+ *     print-and-exit behaviour, see nns_cudacall.hpp).
+ *
+ * Semantics (identical to the reference's V0, core.cu:31-52): for every query
+ * i, the index j in [0,n) minimising the fp32 value
+ *     sum_{t=0..k-1, t ascending} fl( fl(q[i][t] - r[j][t])^2 )
+ * (un-contracted IEEE fp32, starting from 0), the LOWEST index winning exact
+ * ties; a NaN or +INF distance is never selected; a row with no selectable
+ * distance returns index 0.  Indices are bit-exact against V0; the returned
+ * distance is that same fp32 value (bit-equal, tolerance 0 ulp).
+ *
+ * Layouts: queries s_points[m][k], refs r_points[n][k], row-major fp32
+ * (core.cu:41); results int32[m], 0-based global ref index.
+ *
+ * Threading: one caller thread per nns_index; the whole-call entry points are
+ * re-entrant (no globals).  All device work of the split API is enqueued on
+ * the caller's HIP stream and is asynchronous unless stated.
+ */
+#ifndef NNS_MI355X_H
+#define NNS_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNS_VERSION_MAJOR 0
+#define NNS_VERSION_MINOR 1
+
+/* status codes */
+enum {
+    NNS_OK = 0,
+    NNS_ERR_INVALID = 1,   /* bad argument (k,m,n <= 0, null pointer, ...) */
+    NNS_ERR_HIP = 2,       /* a HIP runtime call failed: see nns_last_error() */
+    NNS_ERR_NOMEM = 3,     /* host or device allocation failed */
+    NNS_ERR_NODEVICE = 4,  /* no gfx950 device visible */
+    NNS_ERR_UNSUPPORTED = 5
+};
+
+/* path selection flags (nns_index_create / nns_search_f32_ex) */
+enum {
+    NNS_PATH_AUTO = 0,   /* MFMA filter for k >= 32, exact VALU kernels below */
+    NNS_PATH_EXACT = 1,  /* exact per-pair kernels only (V1..V9 arithmetic re-expressed) */
+    NNS_PATH_MFMA = 2,   /* -2*Q*R^T MFMA filter + exact re-rank (k padded to the tile K) */
+    NNS_PATH_MASK = 3,
+    NNS_PROFILE = 16     /* record HIP-event timings per stage (adds syncs at read-out) */
+};
+
+/*
+ * Packed (distance, index) key: (fp32 bits of the V0 distance << 32) | index.
+ * Distances are >= +0, so unsigned (and, below 2^63, signed) integer order is
+ * (distance, then index) lexicographic order: min over keys == V0's argmin
+ * rule at every reduction level, including an RCCL ncclMin
+ * all-reduce on int64/uint64.  NNS_KEY_NONE marks "no selectable distance"
+ * (V0 leaves minSum = INFINITY, index = 0: core.cu:34-35).
+ */
+typedef uint64_t nns_key;
+#define NNS_KEY_NONE 0x7F80000000000000ull
+
+/* opaque handle: one device-resident, prepared shard of reference points */
+typedef struct nns_index nns_index;
+
+/* per-search statistics (NNS_PROFILE adds the *_ms fields) */
+typedef struct nns_stats {
+    int path;              /* NNS_PATH_EXACT or NNS_PATH_MFMA actually taken */
+    int k_tile;            /* K of the MFMA tile (k padded up), 0 on the exact path */
+    int splits;            /* ref-range splits of the filter grid */
+    int ambiguous;         /* queries re-ranked by the exact scan (filter margin < tau) */
+    int nonfinite;         /* 1 if NaN/INF/huge inputs forced the exact path */
+    float prep_refs_ms;    /* K2 on refs (index create) */
+    float prep_queries_ms; /* K2 on queries */
+    float filter_ms;       /* K3 MFMA filter */
+    float finalize_ms;     /* K5 merge + exact distance of winners */
+    float rerank_ms;       /* exact scan of ambiguous queries */
+    float exact_ms;        /* exact path kernels (K1) */
+    float total_ms;        /* all device work of the last search */
+} nns_stats;
+
+/* ---- whole-call drop-ins (host pointers; alloc + H2D + kernels + D2H) ------ */
+
+/* Replaces vN::cudaCall (core.cu:23-29): *results is malloc()'d (m ints) and
+ * owned by the caller (free()).  Uses device 0.  Returns NNS_OK or an error
+ * (never exits). */
+int nns_search_f32(int k, int m, int n, const float *s_points,
+                   const float *r_points, int **results);
+
+/* Same search into caller-provided host buffers; dist_out may be NULL.
+ * num_shards > 1 splits the refs into contiguous ceil(n/num_shards) ranges
+ * (the V8/V9 split rule, core.cu:781-791) searched one after another on the
+ * one device and merged with nns_keys_min — the single-GPU rehearsal of the
+ * multi-GPU path.  flags: NNS_PATH_*. */
+int nns_search_f32_ex(int k, int m, int n, const float *s_points,
+                      const float *r_points, int *idx_out, float *dist_out,
+                      int num_shards, unsigned flags, int device);
+
+/* ---- split API (device-resident buffers, caller's stream) ------------------ */
+
+/* Prepare a shard of n reference points r_dev[n][k] (device memory, fp32 AoS)
+ * for searching.  index_base is added to every returned index (the shard's
+ * offset into the global ref set, core.cu:827-829).  r_dev must stay valid and
+ * unchanged for the life of the index (the exact re-rank reads the original
+ * values).  stream: a hipStream_t (NULL = default stream). */
+int nns_index_create(nns_index **out, int device, int k, int n,
+                     const float *r_dev, int64_t index_base, unsigned flags,
+                     void *stream);
+int nns_index_destroy(nns_index *ix);
+
+/* Re-run the reference pre-pass (K2) on the same buffer, e.g. after the caller
+ * rewrote r_dev in place, or to time it. */
+int nns_index_refresh(nns_index *ix, void *stream);
+
+/* keys_dev[i] = packed (V0 distance, index_base + argmin) of query i over this
+ * shard, or NNS_KEY_NONE.  q_dev[m][k] fp32 AoS in device memory. */
+int nns_index_search(nns_index *ix, int m, const float *q_dev,
+                     nns_key *keys_dev, void *stream);
+
+int nns_index_stats(nns_index *ix, nns_stats *out);
+
+/* inout[i] = min(inout[i], other[i]) : the cross-shard merge operator. */
+int nns_keys_min(nns_key *inout_dev, const nns_key *other_dev, int m, void *stream);
+
+/* idx_dev[i] = index of keys_dev[i] (0 for NNS_KEY_NONE, as V0); dist_dev
+ * (optional) = its fp32 distance (+INF for NNS_KEY_NONE). */
+int nns_keys_unpack(const nns_key *keys_dev, int m, int *idx_dev,
+                    float *dist_dev, void *stream);
+
+/* Deterministic synthetic clouds: dev[i] = u24(splitmix64(seed, offset+i)) * 2^-24
+ * in [0,1) — bit-identical to oracle/v0_oracle.c:nns_rng_fill on the CPU. */
+int nns_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset,
+                     void *stream);
+
+/* Diagnostic: one 32x32 tile through the filter's MFMA k-order.  a[32][kt],
+ * b[32][kt], c0[32], out[32][32] are HOST buffers; out[i][j] = the MFMA FMA chain
+ * of sum_t a[i][t] * b[j][t] seeded with c0[i].  Lets a test compare the hardware's
+ * v_mfma_f32_32x32x2_f32 against a host fmaf() chain (the error model behind the
+ * filter's proof margin). */
+int nns_selftest_mfma(int kt, const float *a, const float *b, const float *c0, float *out);
+
+/* ---- misc ------------------------------------------------------------------ */
+int nns_device_count(void);
+const char *nns_strerror(int status);
+const char *nns_last_error(void); /* thread-local detail of the last failure */
+int nns_version(void);            /* major * 1000 + minor */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNS_MI355X_H */

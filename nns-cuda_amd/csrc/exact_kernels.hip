@@ -1,0 +1,397 @@
+// exact_kernels.hip — K1: exact per-pair distance + argmin kernels (gfx950 VALU),
+// and the small packed-key utilities (K5's merge operator).
+//
+// These re-express the reference's V1..V7 "distance + argmin" kernels
+// (core.cu:58-122 get_dis_kernel/get_min_kernel, core.cu:215-257, 307-349,
+// 589-633 fused cudaCallKernel) with V0's exact arithmetic (core.cu:38-44):
+// fp32 diff, un-contracted mul then add, t ascending, strict '>' so the lowest
+// index wins ties.  The distance matrix is never materialised and
+// every reduction level compares packed (distance, index) keys, so the result is
+// bit-identical to V0 by construction.
+//
+// Two geometries:
+//   K1a  lane = query   (many queries, small k):  the query sits in k VGPRs, the
+//        refs are wave-uniform and arrive through scalar loads straight from the
+//        AoS array (12 B per ref at k = 3: no transpose needed, unlike the
+//        reference's mat_inv_kernel core.cu:293-306); grid = query tiles x ref
+//        splits (the V7 idea, core.cu:662, without its host second stage).
+//   K1b  lane = ref     (few queries or large k): a tile of queries in LDS read
+//        by broadcast, each lane walks its own ref row; used for the exact
+//        re-rank of ambiguous queries behind the MFMA filter and for m ~ 1.
+#include "nns_internal.h"
+
+namespace nns {
+
+// ---------------------------------------------------------------------------
+// key utilities
+// ---------------------------------------------------------------------------
+__global__ void keys_fill_kernel(nns_key *keys, int m, nns_key v)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) keys[i] = v;
+}
+
+__global__ void keys_min_kernel(nns_key *inout, const nns_key *other, int m)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) {
+        nns_key a = inout[i], b = other[i];
+        inout[i] = b < a ? b : a;
+    }
+}
+
+__global__ void keys_unpack_kernel(const nns_key *keys, int m, int *idx, float *dist)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) {
+        nns_key kx = keys[i];
+        idx[i] = (int)(uint32_t)(kx & 0xFFFFFFFFull);  // NNS_KEY_NONE -> 0, as V0
+        if (dist) dist[i] = __uint_as_float((uint32_t)(kx >> 32));
+    }
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// same stream as oracle/v0_oracle.c:nns_rng_fill
+__global__ void fill_uniform_kernel(float *out, size_t count, uint64_t s, uint64_t offset)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) {
+        uint64_t h = mix64(s ^ ((offset + i) * 0xD1342543DE82EF95ull));
+        out[i] = (float)(h >> 40) * (1.0f / 16777216.0f);
+    }
+}
+
+int launch_keys_fill(nns_key *keys, int m, nns_key value, hipStream_t st)
+{
+    hipLaunchKernelGGL(keys_fill_kernel, dim3(divup(m, 256)), dim3(256), 0, st, keys, m, value);
+    NNS_HIP(hipGetLastError());
+    return NNS_OK;
+}
+int launch_keys_min(nns_key *inout, const nns_key *other, int m, hipStream_t st)
+{
+    hipLaunchKernelGGL(keys_min_kernel, dim3(divup(m, 256)), dim3(256), 0, st, inout, other, m);
+    NNS_HIP(hipGetLastError());
+    return NNS_OK;
+}
+int launch_keys_unpack(const nns_key *keys, int m, int *idx, float *dist, hipStream_t st)
+{
+    hipLaunchKernelGGL(keys_unpack_kernel, dim3(divup(m, 256)), dim3(256), 0, st, keys, m, idx, dist);
+    NNS_HIP(hipGetLastError());
+    return NNS_OK;
+}
+int launch_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset, hipStream_t st)
+{
+    // host-side first mix, exactly as the oracle does (s = mix64(seed))
+    uint64_t x = seed + 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x = x ^ (x >> 31);
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks == 0) return NNS_OK;
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dev, count, x, offset);
+    NNS_HIP(hipGetLastError());
+    return NNS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// wave64 / workgroup key reduction
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ nns_key wave_min_key(nns_key v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)v, off, 64);
+        uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
+        nns_key o = ((nns_key)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// K1a: lane = query, wave-uniform refs
+// ---------------------------------------------------------------------------
+constexpr int K1A_CHUNK = 8;   // refs whose distances are kept live for the chunk-min
+
+template <int K>
+__global__ __launch_bounds__(256) void exact_lane_query_kernel(
+    int m, int n, int refs_per_split, const float *__restrict__ q,
+    const float *__restrict__ r, int64_t index_base, nns_key *__restrict__ keys,
+    int use_atomic)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * refs_per_split;
+    int j1 = j0 + refs_per_split;
+    if (j1 > n) j1 = n;
+
+    float qv[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) qv[t] = (qi < m) ? q[(size_t)qi * K + t] : 0.0f;
+
+    float best = __builtin_inff();
+    int bidx = 0;
+    int j = j0;
+    // Chunked scan: per pair only the 3K distance ops + one v_min; the index of a
+    // new minimum is recovered in a (rare, wave-uniform) branch.  Ascending j and
+    // strict '<' keep V0's first-minimum rule inside the lane.
+    for (; j + K1A_CHUNK <= j1; j += K1A_CHUNK) {
+        float d[K1A_CHUNK];
+#pragma unroll
+        for (int c = 0; c < K1A_CHUNK; ++c) {
+            const float *rj = r + (size_t)(j + c) * K;   // wave-uniform -> s_load
+            float sum = 0.0f;
+#pragma unroll
+            for (int t = 0; t < K; ++t) sum = v0_step(sum, qv[t], rj[t]);
+            d[c] = sum;
+        }
+        float cmin = d[0];
+#pragma unroll
+        for (int c = 1; c < K1A_CHUNK; ++c) cmin = fminf(cmin, d[c]);  // NaN-ignoring min
+        const bool imp = cmin < best;                                  // false for NaN / INF
+        if (__builtin_amdgcn_ballot_w64(imp) != 0ull) {
+            if (imp) {
+                best = cmin;
+#pragma unroll
+                for (int c = K1A_CHUNK - 1; c >= 0; --c)
+                    if (d[c] == cmin) bidx = j + c;   // lowest index in the chunk wins
+            }
+        }
+    }
+    for (; j < j1; ++j) {
+        const float *rj = r + (size_t)j * K;
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < K; ++t) sum = v0_step(sum, qv[t], rj[t]);
+        if (best > sum) {
+            best = sum;
+            bidx = j;
+        }
+    }
+    if (qi < m) {
+        const nns_key key = make_key(best, index_base + bidx);
+        if (use_atomic)
+            atomicMin((unsigned long long *)&keys[qi], (unsigned long long)key);
+        else
+            keys[qi] = key;
+    }
+}
+
+template <int K>
+static int launch_k1a(int m, int n, const float *q, const float *r, int64_t base,
+                      nns_key *keys, hipStream_t st)
+{
+    const int qtiles = divup(m, 256);
+    const int qwaves = divup(m, 64);
+    // enough waves to fill 256 CUs x 4 SIMDs a few times over, >= 256 refs per split
+    int splits = divup(16384, qwaves);
+    const int max_splits = divup(n, 256);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    int per = divup(n, splits);
+    per = divup(per, K1A_CHUNK) * K1A_CHUNK;
+    splits = divup(n, per);
+    if (splits > 1) NNS_TRY(launch_keys_fill(keys, m, NNS_KEY_NONE, st));
+    hipLaunchKernelGGL(exact_lane_query_kernel<K>, dim3(qtiles, splits), dim3(256), 0, st,
+                       m, n, per, q, r, base, keys, splits > 1 ? 1 : 0);
+    NNS_HIP(hipGetLastError());
+    return NNS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// K1b: lane = ref, query tile in LDS (broadcast reads)
+// ---------------------------------------------------------------------------
+template <int QT, int VEC>
+__global__ __launch_bounds__(256) void exact_lane_ref_kernel(
+    int k, int n, const float *__restrict__ q, const float *__restrict__ r,
+    const int *__restrict__ qlist, const int *__restrict__ qcount, int mq,
+    int64_t index_base, nns_key *__restrict__ keys)
+{
+    extern __shared__ __attribute__((aligned(16))) float sq[];  // [QT][k]
+    __shared__ nns_key wkeys[4][QT];
+    const int nq = qlist ? *qcount : mq;
+    const int tid = threadIdx.x;
+
+    for (int g = blockIdx.y; g * QT < nq; g += gridDim.y) {
+        __syncthreads();
+        for (int e = tid; e < QT * k; e += 256) {
+            const int u = e / k, t = e - u * k;
+            const int qslot = g * QT + u;
+            float v = 0.0f;
+            if (qslot < nq) {
+                const int qi = qlist ? qlist[qslot] : qslot;
+                v = q[(size_t)qi * k + t];
+            }
+            sq[e] = v;
+        }
+        __syncthreads();
+
+        float best[QT];
+        int bidx[QT];
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+            best[u] = __builtin_inff();
+            bidx[u] = 0;
+        }
+        for (int j = blockIdx.x * 256 + tid; j < n; j += gridDim.x * 256) {
+            const float *rj = r + (size_t)j * k;
+            float sum[QT];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) sum[u] = 0.0f;
+            if (VEC == 4) {
+                for (int t = 0; t < k; t += 4) {
+                    const float4 rv = *reinterpret_cast<const float4 *>(rj + t);
+#pragma unroll
+                    for (int u = 0; u < QT; ++u) {
+                        const float4 qv = *reinterpret_cast<const float4 *>(&sq[u * k + t]);
+                        float s = sum[u];
+                        s = v0_step(s, qv.x, rv.x);
+                        s = v0_step(s, qv.y, rv.y);
+                        s = v0_step(s, qv.z, rv.z);
+                        s = v0_step(s, qv.w, rv.w);
+                        sum[u] = s;
+                    }
+                }
+            } else {
+                for (int t = 0; t < k; ++t) {
+                    const float rv = rj[t];
+#pragma unroll
+                    for (int u = 0; u < QT; ++u) sum[u] = v0_step(sum[u], sq[u * k + t], rv);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < QT; ++u)
+                if (best[u] > sum[u]) {   // strict: first (lowest j) minimum of this lane
+                    best[u] = sum[u];
+                    bidx[u] = j;
+                }
+        }
+        // lanes -> wave -> workgroup -> global, always on packed keys
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+            nns_key key = wave_min_key(make_key(best[u], index_base + bidx[u]));
+            if (lane == 0) wkeys[wave][u] = key;
+        }
+        __syncthreads();
+        if (tid < QT) {
+            nns_key key = wkeys[0][tid];
+            for (int w = 1; w < 4; ++w) key = wkeys[w][tid] < key ? wkeys[w][tid] : key;
+            const int qslot = g * QT + tid;
+            if (qslot < nq) {
+                const int qi = qlist ? qlist[qslot] : qslot;
+                atomicMin((unsigned long long *)&keys[qi], (unsigned long long)key);
+            }
+        }
+    }
+}
+
+template <int QT>
+static int launch_k1b_t(int k, int n, const float *q, const float *r, const int *qlist,
+                        const int *qcount, int mq, int groups, int64_t base, nns_key *keys,
+                        hipStream_t st)
+{
+    const bool vec = (k % 4 == 0) && (((uintptr_t)r & 15) == 0);
+    const size_t lds = (size_t)QT * k * sizeof(float);
+    int xblocks = divup(n, 256);
+    // about 8 workgroups per CU in total; refs are strided over gridDim.x
+    int target = divup(2048, groups);
+    if (target < 1) target = 1;
+    if (xblocks > target) xblocks = target;
+    dim3 grid(xblocks, groups);
+    if (vec) {
+        auto kern = exact_lane_ref_kernel<QT, 4>;
+        if (lds > 48 * 1024)
+            NNS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k, n, q, r, qlist, qcount, mq, base, keys);
+    } else {
+        auto kern = exact_lane_ref_kernel<QT, 1>;
+        if (lds > 48 * 1024)
+            NNS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k, n, q, r, qlist, qcount, mq, base, keys);
+    }
+    NNS_HIP(hipGetLastError());
+    return NNS_OK;
+}
+
+// query-tile width: as wide as the LDS tile (<= 64 KiB) and the registers allow
+static int pick_qt(int k, int nq)
+{
+    int qt = 32;
+    while (qt > 1 && (size_t)qt * k * 4 > 64 * 1024) qt >>= 1;
+    while (qt > 1 && qt / 2 >= nq) qt >>= 1;
+    if (qt >= 32) return 32;
+    if (qt >= 8) return 8;
+    return qt >= 4 ? 4 : 1;
+}
+
+static int launch_k1b(int k, int n, const float *q, const float *r, const int *qlist,
+                      const int *qcount, int mq, int qt, int groups, int64_t base,
+                      nns_key *keys, hipStream_t st)
+{
+    switch (qt) {
+    case 32: return launch_k1b_t<32>(k, n, q, r, qlist, qcount, mq, groups, base, keys, st);
+    case 8: return launch_k1b_t<8>(k, n, q, r, qlist, qcount, mq, groups, base, keys, st);
+    case 4: return launch_k1b_t<4>(k, n, q, r, qlist, qcount, mq, groups, base, keys, st);
+    default: return launch_k1b_t<1>(k, n, q, r, qlist, qcount, mq, groups, base, keys, st);
+    }
+}
+
+static int check_k(int k)
+{
+    if ((size_t)k * 4 > 64 * 1024) {
+        set_error("exact path: k = %d exceeds the LDS query tile (k <= 16384)", k);
+        return NNS_ERR_UNSUPPORTED;
+    }
+    return NNS_OK;
+}
+
+int launch_exact_search(int k, int m, int n, const float *q, const float *r,
+                        int64_t index_base, nns_key *keys, hipStream_t st)
+{
+    // K1a needs enough queries to fill lanes; its query lives in K registers
+    if (m >= 64) {
+        switch (k) {
+        case 1: return launch_k1a<1>(m, n, q, r, index_base, keys, st);
+        case 2: return launch_k1a<2>(m, n, q, r, index_base, keys, st);
+        case 3: return launch_k1a<3>(m, n, q, r, index_base, keys, st);
+        case 4: return launch_k1a<4>(m, n, q, r, index_base, keys, st);
+        case 8: return launch_k1a<8>(m, n, q, r, index_base, keys, st);
+        case 16: return launch_k1a<16>(m, n, q, r, index_base, keys, st);
+        default: break;
+        }
+    }
+    NNS_TRY(check_k(k));
+    NNS_TRY(launch_keys_fill(keys, m, NNS_KEY_NONE, st));
+    const int qt = pick_qt(k, m);
+    int groups = divup(m, qt);
+    if (groups > 4096) groups = 4096;   // grid.y strides over the rest
+    return launch_k1b(k, n, q, r, nullptr, nullptr, m, qt, groups, index_base, keys, st);
+}
+
+int launch_exact_listed(int k, int n, const float *q, const float *r, const int *qlist,
+                        const int *qcount, int max_listed, int64_t index_base,
+                        nns_key *keys, hipStream_t st)
+{
+    if (max_listed <= 0) return NNS_OK;
+    NNS_TRY(check_k(k));
+    // The number of listed queries lives on the device (no host sync): a fixed
+    // grid of 8 query-group rows strides over however many 32-query groups there
+    // are, so a handful of ambiguous queries and a pathological all-ambiguous
+    // batch both keep ~2048 workgroups busy.
+    const int qt = pick_qt(k, max_listed >= 32 ? 32 : max_listed);
+    int groups = divup(max_listed, qt);
+    if (groups > 8) groups = 8;
+    return launch_k1b(k, n, q, r, qlist, qcount, 0, qt, groups, index_base, keys, st);
+}
+
+}  // namespace nns

@@ -1,0 +1,482 @@
+// nns_api.hip — the C ABI of include/nns.h: host orchestration of K1..K5.
+//
+// Mirrors the host half of the reference's vN::cudaCall (alloc -> H2D -> layout
+// prep -> kernels -> D2H -> free; core.cu:123-151 for V1, 634-697 for V7,
+// 761-853 for V8), split so that the device-resident part (index create +
+// search on the caller's stream) can be timed and sharded on its own.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#include "nns_internal.h"
+
+namespace nns {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace nns
+
+using namespace nns;
+
+enum { EV_BEGIN = 0, EV_QPREP, EV_FILTER, EV_FINAL, EV_RERANK, EV_END, EV_R0, EV_R1, EV_COUNT };
+
+struct nns_index {
+    int device = 0;
+    int k = 0, n = 0;
+    int64_t base = 0;
+    unsigned flags = 0;
+    int path = NNS_PATH_EXACT;
+    const float *r_dev = nullptr;
+    bool profile = false;
+    bool refs_bad = false;
+
+    // MFMA path, ref side
+    FilterGeom geom{};
+    float *rimg = nullptr, *rnorm = nullptr, *mean = nullptr;
+    double *mean_ws = nullptr;
+    DevScalars *scal = nullptr;
+
+    // MFMA path, query side (grown on demand)
+    int m_cap = 0;
+    float *qimg = nullptr, *qnorm = nullptr;
+    Partial *partials = nullptr;
+    size_t partials_cap = 0;
+    int *amb_list = nullptr;
+
+    hipEvent_t ev[EV_COUNT] = {};
+    bool ev_valid = false;
+    bool searched = false;
+    int last_m = 0;
+    int last_path = NNS_PATH_EXACT;
+};
+
+static int ensure_device_ok(int device)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt < 1) {
+        set_error("no HIP device visible (the HIP path has no CPU fallback)");
+        return NNS_ERR_NODEVICE;
+    }
+    if (device < 0 || device >= cnt) {
+        set_error("device %d out of range (%d visible)", device, cnt);
+        return NNS_ERR_INVALID;
+    }
+    NNS_HIP(hipSetDevice(device));
+    return NNS_OK;
+}
+
+static int prep_refs(nns_index *ix, hipStream_t st)
+{
+    const FilterGeom &g = ix->geom;
+    NNS_HIP(hipMemsetAsync(ix->scal, 0, sizeof(DevScalars), st));
+    NNS_TRY(launch_prep_mean(ix->k, g.kt, ix->n, ix->r_dev, ix->mean_ws, ix->mean,
+                             &ix->scal->r_maxabs_bits, st));
+    NNS_TRY(launch_prep_image(ix->k, g.kt, ix->n, g.n_pad, ix->r_dev, ix->mean, -2.0f,
+                              INFINITY, ix->rimg, ix->rnorm, &ix->scal->ymax2_bits, nullptr, st));
+    return NNS_OK;
+}
+
+extern "C" {
+
+int nns_version(void) { return NNS_VERSION_MAJOR * 1000 + NNS_VERSION_MINOR; }
+
+const char *nns_last_error(void) { return g_err; }
+
+const char *nns_strerror(int status)
+{
+    switch (status) {
+    case NNS_OK: return "ok";
+    case NNS_ERR_INVALID: return "invalid argument";
+    case NNS_ERR_HIP: return "HIP runtime error";
+    case NNS_ERR_NOMEM: return "out of memory";
+    case NNS_ERR_NODEVICE: return "no gfx950 device";
+    case NNS_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+    }
+}
+
+int nns_device_count(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+int nns_index_destroy(nns_index *ix)
+{
+    if (!ix) return NNS_OK;
+    (void)hipSetDevice(ix->device);
+    hipFree(ix->rimg);
+    hipFree(ix->rnorm);
+    hipFree(ix->mean);
+    hipFree(ix->mean_ws);
+    hipFree(ix->scal);
+    hipFree(ix->qimg);
+    hipFree(ix->qnorm);
+    hipFree(ix->partials);
+    hipFree(ix->amb_list);
+    if (ix->ev_valid)
+        for (int i = 0; i < EV_COUNT; ++i) hipEventDestroy(ix->ev[i]);
+    delete ix;
+    return NNS_OK;
+}
+
+int nns_index_create(nns_index **out, int device, int k, int n, const float *r_dev,
+                     int64_t index_base, unsigned flags, void *stream)
+{
+    if (!out || !r_dev || k <= 0 || n <= 0) {
+        set_error("nns_index_create: k, n must be > 0 and pointers non-null (k=%d n=%d)", k, n);
+        return NNS_ERR_INVALID;
+    }
+    if (index_base < 0 || index_base + (int64_t)n > 0x7FFFFFFFll) {
+        set_error("nns_index_create: index_base + n exceeds int32 (the reference's index type)");
+        return NNS_ERR_INVALID;
+    }
+    *out = nullptr;
+    NNS_TRY(ensure_device_ok(device));
+    hipStream_t st = (hipStream_t)stream;
+
+    nns_index *ix = new (std::nothrow) nns_index();
+    if (!ix) return NNS_ERR_NOMEM;
+    ix->device = device;
+    ix->k = k;
+    ix->n = n;
+    ix->base = index_base;
+    ix->flags = flags;
+    ix->r_dev = r_dev;
+    ix->profile = (flags & NNS_PROFILE) != 0;
+
+    int path = flags & NNS_PATH_MASK;
+    if (path == NNS_PATH_AUTO) path = (k >= 32 && k <= 128) ? NNS_PATH_MFMA : NNS_PATH_EXACT;
+    if (path == NNS_PATH_MFMA && k > 128) {
+        set_error("NNS_PATH_MFMA: k = %d > 128 is not tiled yet (use NNS_PATH_AUTO/EXACT)", k);
+        delete ix;
+        return NNS_ERR_UNSUPPORTED;
+    }
+    ix->path = path;
+
+    int rc = NNS_OK;
+    do {
+        if (ix->profile) {
+            bool ok = true;
+            for (int i = 0; i < EV_COUNT; ++i) ok = ok && hipEventCreate(&ix->ev[i]) == hipSuccess;
+            if (!ok) {
+                set_error("hipEventCreate failed");
+                rc = NNS_ERR_HIP;
+                break;
+            }
+            ix->ev_valid = true;
+        }
+        if (path == NNS_PATH_MFMA) {
+            if ((rc = filter_plan(k, 1, n, &ix->geom)) != NNS_OK) break;
+            const FilterGeom &g = ix->geom;
+            size_t ws = 0;
+            prep_workspace_bytes(g.kt, &ws);
+            if (hipMalloc(&ix->rimg, (size_t)g.n_pad * g.kt * sizeof(float)) != hipSuccess ||
+                hipMalloc(&ix->rnorm, (size_t)g.n_pad * sizeof(float)) != hipSuccess ||
+                hipMalloc(&ix->mean, (size_t)g.kt * sizeof(float)) != hipSuccess ||
+                hipMalloc(&ix->mean_ws, ws) != hipSuccess ||
+                hipMalloc(&ix->scal, sizeof(DevScalars)) != hipSuccess) {
+                set_error("nns_index_create: device allocation failed (n_pad=%d kt=%d)", g.n_pad, g.kt);
+                rc = NNS_ERR_NOMEM;
+                break;
+            }
+            if (ix->profile) hipEventRecord(ix->ev[EV_R0], st);
+            if ((rc = prep_refs(ix, st)) != NNS_OK) break;
+            if (ix->profile) hipEventRecord(ix->ev[EV_R1], st);
+            // index build is synchronous: learn whether the refs void the error bound
+            DevScalars h{};
+            if (hipMemcpyAsync(&h, ix->scal, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) {
+                set_error("nns_index_create: readback failed: %s", hipGetErrorString(hipGetLastError()));
+                rc = NNS_ERR_HIP;
+                break;
+            }
+            ix->refs_bad = h.r_maxabs_bits >= 0x5BB1A2BCu;   // NaN / INF / |v| >= 1e17
+        }
+    } while (0);
+    if (rc != NNS_OK) {
+        nns_index_destroy(ix);
+        return rc;
+    }
+    *out = ix;
+    return NNS_OK;
+}
+
+int nns_index_refresh(nns_index *ix, void *stream)
+{
+    if (!ix) return NNS_ERR_INVALID;
+    NNS_TRY(ensure_device_ok(ix->device));
+    if (ix->path != NNS_PATH_MFMA) return NNS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (ix->profile) hipEventRecord(ix->ev[EV_R0], st);
+    NNS_TRY(prep_refs(ix, st));
+    if (ix->profile) hipEventRecord(ix->ev[EV_R1], st);
+    return NNS_OK;
+}
+
+static int ensure_query_ws(nns_index *ix, int m)
+{
+    FilterGeom g = ix->geom;
+    FilterGeom gq{};
+    NNS_TRY(filter_plan(ix->k, m, ix->n, &gq));
+    ix->geom = gq;   // same kt / n_pad / total_slots; m-dependent grid now filled in
+    (void)g;
+    if (gq.m_pad > ix->m_cap) {
+        hipFree(ix->qimg);
+        hipFree(ix->qnorm);
+        hipFree(ix->amb_list);
+        ix->qimg = nullptr;
+        ix->qnorm = nullptr;
+        ix->amb_list = nullptr;
+        ix->m_cap = 0;
+        if (hipMalloc(&ix->qimg, (size_t)gq.m_pad * gq.kt * sizeof(float)) != hipSuccess ||
+            hipMalloc(&ix->qnorm, (size_t)gq.m_pad * sizeof(float)) != hipSuccess ||
+            hipMalloc(&ix->amb_list, (size_t)gq.m_pad * sizeof(int)) != hipSuccess) {
+            set_error("query workspace allocation failed (m_pad=%d)", gq.m_pad);
+            return NNS_ERR_NOMEM;
+        }
+        ix->m_cap = gq.m_pad;
+    }
+    const size_t need = (size_t)gq.splits * gq.m_pad;
+    if (need > ix->partials_cap) {
+        hipFree(ix->partials);
+        ix->partials = nullptr;
+        ix->partials_cap = 0;
+        if (hipMalloc(&ix->partials, need * sizeof(Partial)) != hipSuccess) {
+            set_error("partials allocation failed (%zu entries)", need);
+            return NNS_ERR_NOMEM;
+        }
+        ix->partials_cap = need;
+    }
+    return NNS_OK;
+}
+
+int nns_index_search(nns_index *ix, int m, const float *q_dev, nns_key *keys_dev, void *stream)
+{
+    if (!ix || !q_dev || !keys_dev || m <= 0) {
+        set_error("nns_index_search: m must be > 0 and pointers non-null (m=%d)", m);
+        return NNS_ERR_INVALID;
+    }
+    NNS_TRY(ensure_device_ok(ix->device));
+    hipStream_t st = (hipStream_t)stream;
+    const bool prof = ix->profile;
+    ix->last_m = m;
+
+    if (ix->path != NNS_PATH_MFMA || ix->refs_bad) {
+        if (prof) hipEventRecord(ix->ev[EV_BEGIN], st);
+        NNS_TRY(launch_exact_search(ix->k, m, ix->n, q_dev, ix->r_dev, ix->base, keys_dev, st));
+        if (prof) hipEventRecord(ix->ev[EV_END], st);
+        ix->last_path = NNS_PATH_EXACT;
+        ix->searched = true;
+        return NNS_OK;
+    }
+
+    NNS_TRY(ensure_query_ws(ix, m));
+    const FilterGeom &g = ix->geom;
+    if (prof) hipEventRecord(ix->ev[EV_BEGIN], st);
+    // reset the per-search scalars (q max-abs, ambiguous count); keep the ref-side ones
+    NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned), st));
+    NNS_HIP(hipMemsetAsync(&ix->scal->amb_count, 0, sizeof(int), st));
+    NNS_TRY(launch_prep_image(ix->k, g.kt, m, g.m_pad, q_dev, ix->mean, 1.0f, 0.0f, ix->qimg,
+                              ix->qnorm, nullptr, &ix->scal->q_maxabs_bits, st));
+    if (prof) hipEventRecord(ix->ev[EV_QPREP], st);
+    NNS_TRY(launch_filter_f32(g, ix->qimg, ix->rimg, ix->rnorm, ix->partials, st));
+    if (prof) hipEventRecord(ix->ev[EV_FILTER], st);
+    NNS_TRY(launch_finalize(g, ix->k, m, ix->n, q_dev, ix->r_dev, ix->partials, ix->qnorm, ix->scal,
+                            ix->base, keys_dev, ix->amb_list, st));
+    if (prof) hipEventRecord(ix->ev[EV_FINAL], st);
+    NNS_TRY(launch_exact_listed(ix->k, ix->n, q_dev, ix->r_dev, ix->amb_list, &ix->scal->amb_count,
+                                m, ix->base, keys_dev, st));
+    if (prof) {
+        hipEventRecord(ix->ev[EV_RERANK], st);
+        hipEventRecord(ix->ev[EV_END], st);
+    }
+    ix->last_path = NNS_PATH_MFMA;
+    ix->searched = true;
+    return NNS_OK;
+}
+
+int nns_index_stats(nns_index *ix, nns_stats *out)
+{
+    if (!ix || !out) return NNS_ERR_INVALID;
+    NNS_TRY(ensure_device_ok(ix->device));
+    memset(out, 0, sizeof(*out));
+    out->path = ix->searched ? ix->last_path : ix->path;
+    out->nonfinite = ix->refs_bad ? 1 : 0;
+    if (ix->path == NNS_PATH_MFMA) {
+        out->k_tile = ix->geom.kt;
+        out->splits = ix->geom.splits;
+        NNS_HIP(hipDeviceSynchronize());
+        DevScalars h{};
+        NNS_HIP(hipMemcpy(&h, ix->scal, sizeof(h), hipMemcpyDeviceToHost));
+        out->ambiguous = ix->searched && ix->last_path == NNS_PATH_MFMA ? h.amb_count : 0;
+        if (h.q_maxabs_bits >= 0x5BB1A2BCu) out->nonfinite = 1;
+    }
+    if (ix->profile && ix->ev_valid) {
+        NNS_HIP(hipDeviceSynchronize());
+        float ms = 0;
+        if (ix->path == NNS_PATH_MFMA && hipEventElapsedTime(&ms, ix->ev[EV_R0], ix->ev[EV_R1]) == hipSuccess)
+            out->prep_refs_ms = ms;
+        if (ix->searched) {
+            if (ix->last_path == NNS_PATH_MFMA) {
+                if (hipEventElapsedTime(&ms, ix->ev[EV_BEGIN], ix->ev[EV_QPREP]) == hipSuccess) out->prep_queries_ms = ms;
+                if (hipEventElapsedTime(&ms, ix->ev[EV_QPREP], ix->ev[EV_FILTER]) == hipSuccess) out->filter_ms = ms;
+                if (hipEventElapsedTime(&ms, ix->ev[EV_FILTER], ix->ev[EV_FINAL]) == hipSuccess) out->finalize_ms = ms;
+                if (hipEventElapsedTime(&ms, ix->ev[EV_FINAL], ix->ev[EV_RERANK]) == hipSuccess) out->rerank_ms = ms;
+            } else {
+                if (hipEventElapsedTime(&ms, ix->ev[EV_BEGIN], ix->ev[EV_END]) == hipSuccess) out->exact_ms = ms;
+            }
+            if (hipEventElapsedTime(&ms, ix->ev[EV_BEGIN], ix->ev[EV_END]) == hipSuccess) out->total_ms = ms;
+        }
+        (void)hipGetLastError();
+    }
+    return NNS_OK;
+}
+
+int nns_keys_min(nns_key *inout_dev, const nns_key *other_dev, int m, void *stream)
+{
+    if (!inout_dev || !other_dev || m <= 0) return NNS_ERR_INVALID;
+    return launch_keys_min(inout_dev, other_dev, m, (hipStream_t)stream);
+}
+
+int nns_keys_unpack(const nns_key *keys_dev, int m, int *idx_dev, float *dist_dev, void *stream)
+{
+    if (!keys_dev || !idx_dev || m <= 0) return NNS_ERR_INVALID;
+    return launch_keys_unpack(keys_dev, m, idx_dev, dist_dev, (hipStream_t)stream);
+}
+
+int nns_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset, void *stream)
+{
+    if (!dev && count) return NNS_ERR_INVALID;
+    return launch_fill_uniform(dev, count, seed, offset, (hipStream_t)stream);
+}
+
+int nns_selftest_mfma(int kt, const float *a, const float *b, const float *c0, float *out)
+{
+    if (kt <= 0 || (kt & 7) || !a || !b || !c0 || !out) return NNS_ERR_INVALID;
+    NNS_TRY(ensure_device_ok(0));
+    float *d = nullptr;
+    const size_t na = (size_t)32 * kt, total = 2 * na + 32 + 1024;
+    NNS_HIP(hipMalloc(&d, total * sizeof(float)));
+    int rc = NNS_OK;
+    if (hipMemcpy(d, a, na * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + na, b, na * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + 2 * na, c0, 32 * 4, hipMemcpyHostToDevice) != hipSuccess)
+        rc = NNS_ERR_HIP;
+    if (rc == NNS_OK) rc = launch_mfma_selftest(kt, d, d + na, d + 2 * na, d + 2 * na + 32, nullptr);
+    if (rc == NNS_OK && hipMemcpy(out, d + 2 * na + 32, 1024 * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = NNS_ERR_HIP;
+    if (rc == NNS_ERR_HIP) set_error("nns_selftest_mfma: %s", hipGetErrorString(hipGetLastError()));
+    hipFree(d);
+    return rc;
+}
+
+int nns_search_f32_ex(int k, int m, int n, const float *s_points, const float *r_points,
+                      int *idx_out, float *dist_out, int num_shards, unsigned flags, int device)
+{
+    if (k <= 0 || m <= 0 || n <= 0 || !s_points || !r_points || !idx_out) {
+        set_error("nns_search_f32: k, m, n must be > 0 and pointers non-null (k=%d m=%d n=%d)", k, m, n);
+        return NNS_ERR_INVALID;
+    }
+    if ((int64_t)k * m > 0x7FFFFFFFll * 4 || (int64_t)k * n > 0x7FFFFFFFll * 4) {
+        set_error("nns_search_f32: point set too large for one call");
+        return NNS_ERR_INVALID;
+    }
+    NNS_TRY(ensure_device_ok(device));
+    if (num_shards < 1) num_shards = 1;
+    if (num_shards > n) num_shards = n;   // the reference clamps GPUs to n (core.cu:771-772)
+
+    float *q_d = nullptr, *r_d = nullptr, *dist_d = nullptr;
+    nns_key *keys = nullptr, *keys_tmp = nullptr;
+    int *idx_d = nullptr;
+    hipStream_t st = nullptr;
+    int rc = NNS_OK;
+    nns_index *ix = nullptr;
+    do {
+        const size_t qb = (size_t)m * k * sizeof(float), rb = (size_t)n * k * sizeof(float);
+        if (hipMalloc(&q_d, qb) != hipSuccess || hipMalloc(&r_d, rb) != hipSuccess ||
+            hipMalloc(&keys, (size_t)m * sizeof(nns_key)) != hipSuccess ||
+            hipMalloc(&keys_tmp, (size_t)m * sizeof(nns_key)) != hipSuccess ||
+            hipMalloc(&idx_d, (size_t)m * sizeof(int)) != hipSuccess ||
+            hipMalloc(&dist_d, (size_t)m * sizeof(float)) != hipSuccess) {
+            set_error("nns_search_f32: device allocation failed");
+            rc = NNS_ERR_NOMEM;
+            break;
+        }
+        if (hipMemcpy(q_d, s_points, qb, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(r_d, r_points, rb, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("nns_search_f32: H2D copy failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = NNS_ERR_HIP;
+            break;
+        }
+        // contiguous ceil(n / shards) ranges (reference split rule core.cu:781-791)
+        const int per = divup(n, num_shards);
+        bool first = true;
+        for (int s = 0; s < num_shards && rc == NNS_OK; ++s) {
+            const int beg = s * per;
+            const int cnt = (beg + per <= n) ? per : n - beg;
+            if (cnt <= 0) break;
+            rc = nns_index_create(&ix, device, k, cnt, r_d + (size_t)beg * k, beg, flags, st);
+            if (rc != NNS_OK) break;
+            rc = nns_index_search(ix, m, q_d, first ? keys : keys_tmp, st);
+            if (rc == NNS_OK && !first) rc = nns_keys_min(keys, keys_tmp, m, st);
+            if (rc == NNS_OK && hipStreamSynchronize(st) != hipSuccess) {
+                set_error("nns_search_f32: kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
+                rc = NNS_ERR_HIP;
+            }
+            nns_index_destroy(ix);
+            ix = nullptr;
+            first = false;
+        }
+        if (rc != NNS_OK) break;
+        rc = nns_keys_unpack(keys, m, idx_d, dist_d, st);
+        if (rc != NNS_OK) break;
+        if (hipMemcpy(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+            (dist_out && hipMemcpy(dist_out, dist_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
+            set_error("nns_search_f32: D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = NNS_ERR_HIP;
+        }
+    } while (0);
+    hipFree(q_d);
+    hipFree(r_d);
+    hipFree(keys);
+    hipFree(keys_tmp);
+    hipFree(idx_d);
+    hipFree(dist_d);
+    return rc;
+}
+
+int nns_search_f32(int k, int m, int n, const float *s_points, const float *r_points, int **results)
+{
+    if (!results) {
+        set_error("nns_search_f32: results is null");
+        return NNS_ERR_INVALID;
+    }
+    *results = nullptr;
+    if (m <= 0) {
+        set_error("nns_search_f32: m must be > 0");
+        return NNS_ERR_INVALID;
+    }
+    int *tmp = (int *)malloc(sizeof(int) * (size_t)m);   // caller free()s, as core.cu:31,52
+    if (!tmp) return NNS_ERR_NOMEM;
+    const int rc = nns_search_f32_ex(k, m, n, s_points, r_points, tmp, nullptr, 1, NNS_PATH_AUTO, 0);
+    if (rc != NNS_OK) {
+        free(tmp);
+        return rc;
+    }
+    *results = tmp;
+    return NNS_OK;
+}
+
+}  // extern "C"

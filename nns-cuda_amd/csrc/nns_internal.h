@@ -1,0 +1,131 @@
+// nns_internal.h — shared declarations of the gfx950 nearest-neighbour kernels.
+// (internal; the public boundary is include/nns.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "nns.h"
+
+namespace nns {
+
+// ---- error plumbing ---------------------------------------------------------
+void set_error(const char *fmt, ...);
+
+#define NNS_HIP(call)                                                          \
+    do {                                                                       \
+        hipError_t nns_e_ = (call);                                            \
+        if (nns_e_ != hipSuccess) {                                            \
+            ::nns::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call,     \
+                             hipGetErrorString(nns_e_));                       \
+            return NNS_ERR_HIP;                                                \
+        }                                                                      \
+    } while (0)
+
+#define NNS_TRY(call)                                                          \
+    do {                                                                       \
+        int nns_s_ = (call);                                                   \
+        if (nns_s_ != NNS_OK) return nns_s_;                                   \
+    } while (0)
+
+static inline int divup(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t divup64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- packed keys --------------------------------------------------------------
+// (fp32 bits << 32) | index; distances are >= +0 so integer order == (distance,
+// index) lexicographic order == V0's rule (reference core.cu:44).
+__device__ __forceinline__ nns_key pack_key(float d, uint32_t idx)
+{
+    return ((nns_key)__float_as_uint(d) << 32) | (nns_key)idx;
+}
+
+// V0 never selects +INF or NaN (strict '>' against minSum = INFINITY).
+__device__ __forceinline__ nns_key make_key(float best, int64_t idx)
+{
+    return (best < __builtin_inff()) ? pack_key(best, (uint32_t)idx) : (nns_key)NNS_KEY_NONE;
+}
+
+// ---- V0 arithmetic, spelled so that nothing can contract it -------------------
+// reference core.cu:41-42: diff = q - r; tempSum += diff * diff  (fp32, no FMA)
+__device__ __forceinline__ float v0_step(float sum, float q, float r)
+{
+    const float diff = __fsub_rn(q, r);
+    return __fadd_rn(sum, __fmul_rn(diff, diff));
+}
+
+// ---- tile-image geometry (K2 output, K3 input) ---------------------------------
+// A "block" is 32 points.  Its image is [KT/8][2][32][4] floats:
+//   img[b][h][i][e] = value(point i, dim 8b + 4h + e)
+// i.e. exactly the order in which the 64 lanes of a wave (lane = 32h + i) read
+// float4 #b, so one ds_read_b128 / global_load_dwordx4 per lane is lane-linear
+// (1 KiB contiguous per wave-instruction, bank-conflict free), and the four
+// floats are the operands of MFMA k-steps 4b..4b+3 for that lane
+// (v_mfma_f32_32x32x2_f32: lane supplies A[i = lane&31][k = lane>>5]).
+constexpr int kBlockPts = 32;
+
+struct FilterGeom {
+    int variant;          // filter kernel configuration (filter_f32.hip)
+    int kt;               // K of the tile (k padded up with zeros)
+    int m_pad;            // queries padded to the workgroup's query count
+    int n_pad;            // refs padded to a whole ring slot
+    int total_slots;      // n_pad / (32 * kSlotBlocks)
+    int splits;           // grid.y: contiguous ref ranges
+    int slots_per_split;
+    int qgroups;          // grid.x
+};
+
+// filter partial result per (split, query): top-2 of s = |r'|^2 - 2 q'.r'
+struct __attribute__((aligned(16))) Partial {
+    float m1;  // smallest score
+    float m2;  // second smallest score (over everything else this split saw)
+    int idx;   // shard-local ref index of m1
+    int pad;
+};
+
+// device-side scalars shared between kernels of one index
+struct DevScalars {
+    unsigned r_maxabs_bits;  // max |r| bits (NaN/INF/huge detection)
+    unsigned q_maxabs_bits;  // max |q| bits
+    unsigned ymax2_bits;     // max centred squared norm over refs
+    int amb_count;           // number of ambiguous queries
+    unsigned pad[4];
+};
+
+// ---- launchers (each .hip file owns its kernels) --------------------------------
+// exact_kernels.hip
+int launch_keys_fill(nns_key *keys, int m, nns_key value, hipStream_t st);
+int launch_keys_min(nns_key *inout, const nns_key *other, int m, hipStream_t st);
+int launch_keys_unpack(const nns_key *keys, int m, int *idx, float *dist, hipStream_t st);
+int launch_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset, hipStream_t st);
+// exact search of all m queries (K1a lane=query when k is small, else K1b)
+int launch_exact_search(int k, int m, int n, const float *q, const float *r,
+                        int64_t index_base, nns_key *keys, hipStream_t st);
+// exact scan of the queries listed in qlist[0 .. *qcount) (device memory); keys
+// of listed queries must hold NNS_KEY_NONE on entry (atomic-min merge).
+int launch_exact_listed(int k, int n, const float *q, const float *r,
+                        const int *qlist, const int *qcount, int max_listed,
+                        int64_t index_base, nns_key *keys, hipStream_t st);
+
+// prep_kernels.hip (K2)
+int prep_workspace_bytes(int kt, size_t *bytes);
+int launch_prep_mean(int k, int kt, int n, const float *r, double *partial_ws,
+                     float *mean, unsigned *maxabs_bits, hipStream_t st);
+int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts,
+                      const float *mean, float scale, float pad_norm,
+                      float *img, float *norms, unsigned *max_norm_bits,
+                      unsigned *maxabs_bits, hipStream_t st);
+
+// filter_f32.hip (K3)
+int filter_plan(int k, int m, int n, FilterGeom *g);
+int launch_filter_f32(const FilterGeom &g, const float *qimg, const float *rimg,
+                      const float *rnorm, Partial *partials, hipStream_t st);
+
+int launch_mfma_selftest(int kt, const float *a, const float *b, const float *c0, float *out,
+                         hipStream_t st);
+
+// finalize.hip (K5)
+int launch_finalize(const FilterGeom &g, int k, int m, int n, const float *q,
+                    const float *r, const Partial *partials, const float *qnorm,
+                    DevScalars *scal, int64_t index_base, nns_key *keys,
+                    int *amb_list, hipStream_t st);
+
+}  // namespace nns

@@ -1,0 +1,274 @@
+"""Host-side mirror of the reference's entry point over the C ABI (include/nns.h).
+
+The reference's operator interface for this path is a single C++ function,
+``vN::cudaCall(k, m, n, s_points, r_points, &results)`` (reference
+core.cu:23-29, dispatched through the function pointer of main.cu:7 and called at
+main.cu:74).  ``cudaCall`` below has the same argument order and meaning and the
+same result (a fresh int32 array of m global reference indices); the C++ twin is
+``mi355x::cudaCall`` in csrc/nns_cudacall.hpp.  Everything else here is the
+split (device-resident) API used by the tests and bench.py.
+
+This module is plumbing: ctypes bindings to libnns_mi355x.so (hand-written HIP for
+gfx950).  There is NO CPU fallback: if the library is missing the import raises,
+and every entry point raises ``NNSError`` when the library reports a failure
+(no device, bad arguments, HIP error) — the reference's CHECK macro prints and
+exits (utils.h:16-26); a Python host gets an exception instead.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnns_mi355x.so")
+
+NNS_OK = 0
+NNS_PATH_AUTO, NNS_PATH_EXACT, NNS_PATH_MFMA, NNS_PROFILE = 0, 1, 2, 16
+NNS_KEY_NONE = 0x7F80000000000000
+
+_PATHS = {"auto": NNS_PATH_AUTO, "exact": NNS_PATH_EXACT, "mfma": NNS_PATH_MFMA}
+
+# every symbol include/nns.h declares (tests check the library exports them all)
+ABI_SYMBOLS = (
+    "nns_search_f32", "nns_search_f32_ex", "nns_index_create", "nns_index_destroy",
+    "nns_index_refresh", "nns_index_search", "nns_index_stats", "nns_keys_min",
+    "nns_keys_unpack", "nns_fill_uniform", "nns_device_count", "nns_strerror",
+    "nns_last_error", "nns_version", "nns_selftest_mfma",
+)
+
+
+class NNSError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+    def __init__(self, status: int, where: str, detail: str):
+        super().__init__(f"{where}: status {status} ({detail})")
+        self.status = status
+
+
+class nns_stats(ctypes.Structure):
+    _fields_ = [
+        ("path", ctypes.c_int), ("k_tile", ctypes.c_int), ("splits", ctypes.c_int),
+        ("ambiguous", ctypes.c_int), ("nonfinite", ctypes.c_int),
+        ("prep_refs_ms", ctypes.c_float), ("prep_queries_ms", ctypes.c_float),
+        ("filter_ms", ctypes.c_float), ("finalize_ms", ctypes.c_float),
+        ("rerank_ms", ctypes.c_float), ("exact_ms", ctypes.c_float),
+        ("total_ms", ctypes.c_float),
+    ]
+
+    def asdict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C nns-cuda_amd/csrc`). The HIP extension is the product; there is no CPU fallback.")
+    # If torch is (going to be) in the process, let it bring the HIP runtime first so
+    # that one libamdhip64.so.7 serves both (same SONAME in torch/lib and /opt/rocm).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the host-buffer API
+        pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    c_int, c_vp, c_sz, c_u64, c_i64, c_u = (ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                             ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint)
+    lib.nns_search_f32.argtypes = [c_int, c_int, c_int, c_vp, c_vp, ctypes.POINTER(ctypes.POINTER(c_int))]
+    lib.nns_search_f32_ex.argtypes = [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_u, c_int]
+    lib.nns_index_create.argtypes = [ctypes.POINTER(c_vp), c_int, c_int, c_int, c_vp, c_i64, c_u, c_vp]
+    lib.nns_index_destroy.argtypes = [c_vp]
+    lib.nns_index_refresh.argtypes = [c_vp, c_vp]
+    lib.nns_index_search.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
+    lib.nns_index_stats.argtypes = [c_vp, ctypes.POINTER(nns_stats)]
+    lib.nns_keys_min.argtypes = [c_vp, c_vp, c_int, c_vp]
+    lib.nns_keys_unpack.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
+    lib.nns_fill_uniform.argtypes = [c_vp, c_sz, c_u64, c_u64, c_vp]
+    lib.nns_selftest_mfma.argtypes = [c_int, c_vp, c_vp, c_vp, c_vp]
+    lib.nns_device_count.argtypes = []
+    lib.nns_strerror.argtypes = [c_int]
+    lib.nns_strerror.restype = ctypes.c_char_p
+    lib.nns_last_error.argtypes = []
+    lib.nns_last_error.restype = ctypes.c_char_p
+    lib.nns_version.argtypes = []
+    for name in ABI_SYMBOLS:
+        if name not in ("nns_strerror", "nns_last_error"):
+            getattr(lib, name).restype = c_int
+    return lib
+
+
+lib = _load()
+_libc = ctypes.CDLL(None)
+_libc.free.argtypes = [ctypes.c_void_p]
+
+
+def _check(status: int, where: str) -> None:
+    if status != NNS_OK:
+        detail = lib.nns_last_error().decode() or lib.nns_strerror(status).decode()
+        raise NNSError(status, where, detail)
+
+
+def selftest_mfma(a: np.ndarray, b: np.ndarray, c0: np.ndarray) -> np.ndarray:
+    """out[i][j] of one 32x32 MFMA tile (diagnostic, see include/nns.h)."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    c0 = np.ascontiguousarray(c0, np.float32)
+    assert a.shape == b.shape and a.shape[0] == 32 and c0.shape == (32,)
+    out = np.empty((32, 32), np.float32)
+    _check(lib.nns_selftest_mfma(a.shape[1], a.ctypes.data, b.ctypes.data, c0.ctypes.data, out.ctypes.data),
+           "nns_selftest_mfma")
+    return out
+
+
+def device_count() -> int:
+    return lib.nns_device_count()
+
+
+def _as_f32(a, what: str) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2:
+        raise ValueError(f"{what} must be [points][k]")
+    return a
+
+
+def cudaCall(k: int, m: int, n: int, s_points, r_points) -> np.ndarray:
+    """Drop-in for the reference's ``vN::cudaCall(k, m, n, s_points, r_points, &results)``.
+
+    s_points: m*k fp32 (row-major queries), r_points: n*k fp32 (row-major refs);
+    returns the malloc'd int32[m] result the C ABI hands back, copied into numpy.
+    """
+    s = np.ascontiguousarray(s_points, dtype=np.float32).reshape(-1)
+    r = np.ascontiguousarray(r_points, dtype=np.float32).reshape(-1)
+    if s.size < k * m or r.size < k * n:
+        raise ValueError("point arrays shorter than k*m / k*n")
+    res = ctypes.POINTER(ctypes.c_int)()
+    _check(lib.nns_search_f32(k, m, n, s.ctypes.data, r.ctypes.data, ctypes.byref(res)), "nns_search_f32")
+    try:
+        return np.ctypeslib.as_array(res, shape=(m,)).astype(np.int32, copy=True)
+    finally:
+        _libc.free(res)
+
+
+def search(query_points, reference_points, *, return_distances: bool = False, shards: int = 1,
+           path: str = "auto", device: int = 0):
+    """``search(query_points, reference_points)`` — the entry point BASELINE.json names.
+
+    Host arrays in, nearest-reference index per query out (and, optionally, V0's
+    fp32 squared distance).  ``shards`` > 1 rehearses the multi-GPU ref split on one
+    device (contiguous ceil(n/shards) ranges merged with the packed-key min)."""
+    q = _as_f32(query_points, "query_points")
+    r = _as_f32(reference_points, "reference_points")
+    if q.shape[1] != r.shape[1]:
+        raise ValueError("query and reference dimensionality differ")
+    m, k = q.shape
+    n = r.shape[0]
+    idx = np.empty(m, dtype=np.int32)
+    dist = np.empty(m, dtype=np.float32) if return_distances else None
+    _check(lib.nns_search_f32_ex(k, m, n, q.ctypes.data, r.ctypes.data, idx.ctypes.data,
+                                 dist.ctypes.data if dist is not None else None, shards,
+                                 _PATHS[path], device), "nns_search_f32_ex")
+    return (idx, dist) if return_distances else idx
+
+
+# ---------------------------------------------------------------------------
+# device-resident API (torch tensors are only the owners of device memory)
+# ---------------------------------------------------------------------------
+def _stream_ptr(stream) -> Optional[int]:
+    if stream is None:
+        import torch
+        return torch.cuda.current_stream().cuda_stream or None
+    return getattr(stream, "cuda_stream", stream) or None
+
+
+def fill_uniform(t, seed: int, offset: int = 0, stream=None) -> None:
+    """t[i] = synthetic uniform [0,1) value #(offset+i) of stream `seed` (same bits as
+    oracle nns_rng_fill)."""
+    _check(lib.nns_fill_uniform(t.data_ptr(), t.numel(), seed, offset, _stream_ptr(stream)), "nns_fill_uniform")
+
+
+class Index:
+    """One prepared, device-resident shard of reference points (nns_index)."""
+
+    def __init__(self, refs, *, index_base: int = 0, path: str = "auto", profile: bool = False, stream=None):
+        import torch
+        if refs.dtype != torch.float32 or refs.dim() != 2 or not refs.is_contiguous() or not refs.is_cuda:
+            raise ValueError("refs must be a contiguous fp32 [n][k] tensor on a HIP device")
+        self.refs = refs  # keep alive: the index reads the original values
+        self.n, self.k = refs.shape
+        self.device = refs.device.index or 0
+        flags = _PATHS[path] | (NNS_PROFILE if profile else 0)
+        h = ctypes.c_void_p()
+        _check(lib.nns_index_create(ctypes.byref(h), self.device, self.k, self.n, refs.data_ptr(),
+                                    index_base, flags, _stream_ptr(stream)), "nns_index_create")
+        self._h = h
+
+    def refresh(self, stream=None) -> None:
+        _check(lib.nns_index_refresh(self._h, _stream_ptr(stream)), "nns_index_refresh")
+
+    def search_keys(self, queries, keys=None, stream=None):
+        """Packed (V0 distance, global index) int64 key per query (NNS_KEY_NONE if none)."""
+        import torch
+        if queries.dtype != torch.float32 or queries.dim() != 2 or not queries.is_contiguous():
+            raise ValueError("queries must be a contiguous fp32 [m][k] tensor")
+        if queries.shape[1] != self.k:
+            raise ValueError("query dimensionality differs from the index")
+        m = queries.shape[0]
+        if keys is None:
+            keys = torch.empty(m, dtype=torch.int64, device=queries.device)
+        _check(lib.nns_index_search(self._h, m, queries.data_ptr(), keys.data_ptr(), _stream_ptr(stream)),
+               "nns_index_search")
+        return keys
+
+    def search(self, queries, return_distances: bool = False, stream=None):
+        keys = self.search_keys(queries, stream=stream)
+        return keys_unpack(keys, return_distances=return_distances, stream=stream)
+
+    def stats(self) -> dict:
+        st = nns_stats()
+        _check(lib.nns_index_stats(self._h, ctypes.byref(st)), "nns_index_stats")
+        return st.asdict()
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib.nns_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def keys_min(inout, other, stream=None) -> None:
+    _check(lib.nns_keys_min(inout.data_ptr(), other.data_ptr(), inout.numel(), _stream_ptr(stream)), "nns_keys_min")
+
+
+def keys_unpack(keys, return_distances: bool = False, stream=None):
+    import torch
+    m = keys.numel()
+    idx = torch.empty(m, dtype=torch.int32, device=keys.device)
+    dist = torch.empty(m, dtype=torch.float32, device=keys.device) if return_distances else None
+    _check(lib.nns_keys_unpack(keys.data_ptr(), m, idx.data_ptr(),
+                               dist.data_ptr() if dist is not None else None, _stream_ptr(stream)),
+           "nns_keys_unpack")
+    return (idx, dist) if return_distances else idx
+
+
+def shard_range(n: int, shards: int, rank: int) -> Tuple[int, int]:
+    """Contiguous ceil(n/shards) split of the refs, last shard takes the remainder
+    (reference core.cu:781-791).  Returns (begin, count); count may be 0."""
+    per = -(-n // shards)
+    beg = rank * per
+    cnt = max(0, min(per, n - beg))
+    return beg, cnt
+
+
+def allreduce_min_keys(keys, group=None) -> None:
+    """The cross-GPU exchange: ONE min all-reduce of the packed keys (RCCL over xGMI
+    when the process group is 'nccl'; gloo in CPU tests).  Keys are < 2^63, so the
+    signed int64 order torch reduces in is the unsigned key order."""
+    import torch.distributed as dist
+    dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)

@@ -1,0 +1,77 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol of
+include/nns.h, validates arguments, and fails loudly without a device (no CPU
+fallback).  No compute calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(os.path.dirname(pkg.LIB_PATH), "..", "include", "nns.h")).read()
+    declared = set(re.findall(r"\b(nns_[a-z0-9_]+)\s*\(", hdr)) - {"nns_rng_fill"}
+    assert declared == set(pkg.ABI_SYMBOLS), declared ^ set(pkg.ABI_SYMBOLS)
+    raw = ctypes.CDLL(pkg.LIB_PATH)
+    for name in declared:
+        assert getattr(raw, name) is not None
+
+
+def test_version_and_strerror(pkg):
+    assert pkg.lib.nns_version() == 1
+    assert pkg.lib.nns_strerror(0) == b"ok"
+    assert b"invalid" in pkg.lib.nns_strerror(1)
+
+
+def test_no_torch_types_in_header(pkg):
+    hdr = open(os.path.join(os.path.dirname(pkg.LIB_PATH), "..", "include", "nns.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)          # strip comments
+    assert "torch" not in code.lower() and "at::" not in code and "hipStream" not in code
+    assert "#include <hip" not in hdr
+
+
+def test_argument_validation_returns_status_not_exit(pkg):
+    q = np.zeros((4, 3), np.float32)
+    with pytest.raises(pkg.NNSError) as e:
+        pkg.search(q, np.zeros((0, 3), np.float32))
+    assert e.value.status == 1
+    res = ctypes.POINTER(ctypes.c_int)()
+    assert pkg.lib.nns_search_f32(3, 0, 5, q.ctypes.data, q.ctypes.data, ctypes.byref(res)) == 1
+    assert pkg.lib.nns_search_f32(3, 4, 4, q.ctypes.data, q.ctypes.data, None) == 1
+    assert pkg.lib.nns_index_create(None, 0, 3, 4, q.ctypes.data, 0, 0, None) == 1
+    assert b"nns_" in pkg.lib.nns_last_error()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device error path")
+def test_fails_loudly_without_device(pkg):
+    """The product path has no CPU fallback: without a HIP device it must raise."""
+    assert pkg.device_count() == 0
+    q = np.random.default_rng(0).random((4, 3), dtype=np.float32)
+    with pytest.raises(pkg.NNSError) as e:
+        pkg.cudaCall(3, 4, 4, q, q)
+    assert e.value.status == 4   # NNS_ERR_NODEVICE
+    with pytest.raises(pkg.NNSError):
+        pkg.search(q, q)
+
+
+def test_shard_range_is_reference_split(pkg):
+    # core.cu:781-791: contiguous ceil(n/G), last takes the remainder
+    assert [pkg.shard_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 3), (6, 3), (9, 1)]
+    assert [pkg.shard_range(8, 8, r) for r in range(8)] == [(i, 1) for i in range(8)]
+    assert pkg.shard_range(5, 8, 7) == (7, 0)
+    n = 8388608
+    assert sum(pkg.shard_range(n, 8, r)[1] for r in range(8)) == n
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing in the package or bench's product
+    leg may reference it."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "nns-cuda_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pyoracle" not in text and "libv0oracle" not in text and "v0_oracle" not in text.replace(
+                    "oracle/v0_oracle.c:nns_rng_fill", ""), f

@@ -1,0 +1,242 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI, against
+the oracle (V0 restatement) and the committed golden vectors.  Bar: indices
+bit-exact; distances bit-equal (tolerance 0 ulp: the returned distance IS V0's
+fp32 minSum, recomputed with V0's arithmetic on the device)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [0, 1, 2, 3, 4]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _check(pkg, orc, q, r, paths=("auto",), shards=(1,), want=None):
+    with np.errstate(all="ignore"):
+        want_idx, want_dist = orc.v0_search(q, r, threads=8)
+    if want is not None:
+        assert np.array_equal(want_idx, want), "oracle disagrees with the golden vector"
+    for path in paths:
+        if path == "mfma" and q.shape[1] > 128:
+            continue
+        for s in shards:
+            idx, dist = pkg.search(q, r, return_distances=True, shards=s, path=path)
+            bad = np.nonzero(idx != want_idx)[0]
+            assert bad.size == 0, f"path={path} shards={s}: {bad.size} index mismatches, first at query {bad[:5]}"
+            assert np.array_equal(_bits(dist), _bits(want_dist)), f"path={path} shards={s}: distance bits differ"
+
+
+def test_native_library_loaded_on_gpu(pkg):
+    """The tests must run the HIP extension, not a fallback."""
+    assert torch.cuda.is_available()
+    assert pkg.device_count() >= 1
+    with open("/proc/self/maps") as f:
+        assert "libnns_mi355x.so" in f.read()
+
+
+def test_mfma_is_an_fmaf_chain(pkg, orc):
+    """v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain, bit for bit (assumed by tau)."""
+    rng = np.random.default_rng(1)
+    for kt in (64, 128):
+        a = (rng.random((32, kt), dtype=np.float32) - 0.5) * 4
+        b = (rng.random((32, kt), dtype=np.float32) - 0.5) * 4
+        c0 = rng.random(32, dtype=np.float32) * 10
+        out = pkg.selftest_mfma(a, b, c0)
+        # k order of the kernel: step s contracts k = 8(s>>2) + (s&3) then the same + 4
+        order = []
+        for s in range(kt // 2):
+            base = 8 * (s >> 2) + (s & 3)
+            order += [base, base + 4]
+        order = np.array(order)
+        for i in range(32):
+            for j in range(0, 32, 5):
+                want = orc.fmaf_chain(a[i, order], b[j, order], float(c0[i]))
+                assert out[i, j].view(np.uint32) == want.view(np.uint32), (kt, i, j)
+
+
+def test_golden_recipe_samples(pkg, orc, golden_dir):
+    """The reference driver's own samples (main.cu:38-47) on its srand(1000) stream."""
+    z = np.load(f"{golden_dir}/golden_recipe.npz")
+    for i in range(8):
+        if f"s{i}_q" not in z.files:
+            continue
+        k, m, n = (int(v) for v in z[f"s{i}_shape"])
+        q, r, want = z[f"s{i}_q"], z[f"s{i}_r"], z[f"s{i}_idx"]
+        got = pkg.cudaCall(k, m, n, q, r)
+        assert np.array_equal(got, want), f"sample {i} (k={k} m={m} n={n})"
+        _check(pkg, orc, q, r, paths=("auto", "exact"), shards=(1, 3), want=want)
+
+
+def test_golden_recipe_glibc_big_samples(pkg, orc, golden_dir):
+    """Samples 6 and 7 (1024 x 65536) regenerated from the glibc stream."""
+    z = np.load(f"{golden_dir}/golden_recipe.npz")
+    samples = [tuple(int(v) for v in z[f"s{i}_shape"]) for i in range(8)]
+    for i, (k, m, n, q, r) in enumerate(orc.ref_recipe(samples, seed=1000)):
+        fnv = z[f"s{i}_input_fnv"]
+        if orc.fnv1a64(q) != int(fnv[0]) or orc.fnv1a64(r) != int(fnv[1]):
+            pytest.skip("libc rand() stream differs from the fixture's")
+        if i < 6:
+            continue
+        got = pkg.cudaCall(k, m, n, q, r)
+        assert np.array_equal(got, z[f"s{i}_idx"]), f"sample {i}"
+
+
+def test_golden_adversarial_all_paths(pkg, orc, golden_dir):
+    z = np.load(f"{golden_dir}/golden_cases.npz")
+    names = sorted({k.split("__")[0] for k in z.files})
+    for name in names:
+        q, r, want = z[f"{name}__q"], z[f"{name}__r"], z[f"{name}__idx"]
+        _check(pkg, orc, q, r, paths=("auto", "exact", "mfma"), shards=(1, 2, 5), want=want)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_filter_variants_random_128d(pkg, orc, variant):
+    """Every filter configuration, ragged m/n, against the oracle."""
+    os.environ["NNS_FILTER_VARIANT"] = str(variant)
+    try:
+        rng = np.random.default_rng(100 + variant)
+        for (m, n, k) in [(700, 20001, 128), (33, 4097, 64), (1, 130, 128), (513, 63, 100)]:
+            q = rng.random((m, k), dtype=np.float32)
+            r = rng.random((n, k), dtype=np.float32)
+            _check(pkg, orc, q, r, paths=("mfma",), shards=(1, 2))
+    finally:
+        os.environ.pop("NNS_FILTER_VARIANT", None)
+
+
+def test_low_dim_shapes_exact_path(pkg, orc):
+    rng = np.random.default_rng(9)
+    for (m, n, k) in [(4096, 8192, 3), (64, 100000, 3), (1000, 5000, 16), (63, 777, 2), (5, 50000, 8),
+                      (1, 65536, 16), (300, 3000, 7)]:
+        q = rng.random((m, k), dtype=np.float32)
+        r = rng.random((n, k), dtype=np.float32)
+        _check(pkg, orc, q, r, paths=("auto",), shards=(1, 4))
+
+
+def test_ambiguous_queries_take_the_exact_scan(pkg, orc):
+    """Near-duplicate refs force filter margins below tau: the re-rank must decide,
+    and the stats must show it did."""
+    rng = np.random.default_rng(21)
+    base = rng.random((3000, 128), dtype=np.float32)
+    dup = base[:1000].copy()
+    dup[:, 7] = np.nextafter(dup[:, 7], np.float32(2.0))      # 1-ulp twins of 1000 refs
+    r = np.concatenate([base, dup])
+    q = base[:256] + rng.normal(0, 1e-4, (256, 128)).astype(np.float32)
+    _check(pkg, orc, q, r, paths=("mfma",), shards=(1, 2))
+    ix = pkg.Index(torch.from_numpy(r).cuda(), path="mfma")
+    ix.search(torch.from_numpy(q).cuda())
+    st = ix.stats()
+    assert st["path"] == 2 and st["ambiguous"] >= 200, st
+    ix.close()
+
+
+def test_device_api_keys_and_shards(pkg, orc):
+    """Split API: per-shard keys with index_base, merged with nns_keys_min == V0."""
+    rng = np.random.default_rng(33)
+    q = rng.random((500, 128), dtype=np.float32)
+    r = rng.random((9000, 128), dtype=np.float32)
+    r[8000] = r[5]
+    q[0] = r[5]
+    want_idx, want_dist = orc.v0_search(q, r, threads=8)
+    qd = torch.from_numpy(q).cuda()
+    rd = torch.from_numpy(r).cuda()
+    shards = 4
+    keys = None
+    for s in range(shards):
+        beg, cnt = pkg.shard_range(r.shape[0], shards, s)
+        ix = pkg.Index(rd[beg:beg + cnt], index_base=beg)
+        ks = ix.search_keys(qd)
+        if keys is None:
+            keys = ks
+        else:
+            pkg.keys_min(keys, ks)
+        torch.cuda.synchronize()
+        ix.close()
+    idx, dist = pkg.keys_unpack(keys, return_distances=True)
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+    assert np.array_equal(_bits(dist.cpu().numpy()), _bits(want_dist))
+    # keys are plain (dist bits << 32) | idx
+    kk = keys.cpu().numpy()
+    assert np.array_equal((kk >> 32).astype(np.uint32), _bits(want_dist))
+
+
+def test_fill_uniform_matches_oracle_bits(pkg, orc):
+    t = torch.empty(100003, dtype=torch.float32, device="cuda")
+    pkg.fill_uniform(t, seed=1000, offset=12345)
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy(), orc.rng_uniform(100003, 1000, 12345))
+
+
+def test_determinism_bitwise_repeatable(pkg):
+    q = torch.empty((2048, 128), dtype=torch.float32, device="cuda")
+    r = torch.empty((50000, 128), dtype=torch.float32, device="cuda")
+    pkg.fill_uniform(q, 1)
+    pkg.fill_uniform(r, 2)
+    ix = pkg.Index(r)
+    a = ix.search_keys(q).clone()
+    for _ in range(3):
+        b = ix.search_keys(q)
+        assert torch.equal(a, b)
+    ix.close()
+
+
+def test_errors_are_status_codes(pkg):
+    q = np.zeros((4, 200), np.float32)
+    with pytest.raises(pkg.NNSError) as e:
+        pkg.search(q, q, path="mfma")          # k > 128 not tiled on the MFMA path
+    assert e.value.status == 5
+
+
+@pytest.mark.timeout(900)
+def test_headline_shape_properties(pkg, orc):
+    """BASELINE C3 (65536 x 1048576 x 128) at full size: sampled queries against the
+    oracle, planted exact matches, shard invariance of the keys, distances bit-equal to
+    V0's pair arithmetic."""
+    m, n, k = 65536, 1048576, 128
+    q = torch.empty((m, k), dtype=torch.float32, device="cuda")
+    r = torch.empty((n, k), dtype=torch.float32, device="cuda")
+    pkg.fill_uniform(q, 1000, 0)
+    pkg.fill_uniform(r, 1000, m * k)
+    # plant: query i*97 is an exact copy of ref p(i) -> distance +0, index p(i)
+    planted_q = torch.arange(0, 512, device="cuda") * 97
+    planted_r = (torch.arange(0, 512, device="cuda") * 2039 + 17) % n
+    q[planted_q] = r[planted_r]
+    ix = pkg.Index(r)
+    keys = ix.search_keys(q)
+    idx, dist = pkg.keys_unpack(keys, return_distances=True)
+    torch.cuda.synchronize()
+    st = ix.stats()
+    assert st["path"] == 2 and st["nonfinite"] == 0
+    assert st["ambiguous"] < m // 20, st
+    idx_h, dist_h = idx.cpu().numpy(), dist.cpu().numpy()
+    assert np.array_equal(idx_h[planted_q.cpu().numpy()], planted_r.cpu().numpy().astype(np.int32))
+    assert (dist_h[planted_q.cpu().numpy()] == 0).all()
+    assert idx_h.min() >= 0 and idx_h.max() < n
+    # sampled queries against the oracle over ALL refs
+    rh = r.cpu().numpy()
+    sel = np.random.default_rng(0).choice(m, 48, replace=False)
+    qh = q[torch.from_numpy(sel).cuda()].cpu().numpy()
+    want_idx, want_dist = orc.v0_search(qh, rh, threads=16)
+    assert np.array_equal(idx_h[sel], want_idx)
+    assert np.array_equal(_bits(dist_h[sel]), _bits(want_dist))
+    # every returned distance is V0's arithmetic on (q_i, r_idx_i): check a slice on the host
+    for i in range(0, m, 4099):
+        assert _bits(dist_h[i:i + 1])[0] == orc.pair_distance(q[i].cpu().numpy(), rh[idx_h[i]]).view(np.uint32)
+    ix.close()
+    # shard invariance: 2 shards merged == unsharded keys, bit for bit
+    half = n // 2
+    k0 = pkg.Index(r[:half], index_base=0)
+    a = k0.search_keys(q).clone()
+    torch.cuda.synchronize()
+    k0.close()
+    k1 = pkg.Index(r[half:], index_base=half)
+    b = k1.search_keys(q)
+    pkg.keys_min(a, b)
+    torch.cuda.synchronize()
+    k1.close()
+    assert torch.equal(a, keys)
