@@ -1,0 +1,34 @@
+// nns_cudacall.hpp — C++ shim with the reference's exact entry-point type.
+//
+// The reference selects a variant through
+//     void (*func)(int, int, int, float *, float *, int **);        main.cu:7
+// and calls (*func)(k, m, n, s_points, r_points, &results)           main.cu:74
+// with vN::cudaCall (core.cu:23-29 and its siblings).  mi355x::cudaCall has the
+// identical type, so `func = &mi355x::cudaCall;` compiles in a main.cu-style
+// driver unchanged.  Error behaviour mirrors utils.h CHECK (utils.h:16-26):
+// print "Error: file:line, code:N, reason: ..." and exit(1) — the C ABI underneath
+// (include/nns.h) returns status codes and never exits.
+#pragma once
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "nns.h"
+
+namespace mi355x {
+
+inline void cudaCall(int k,            // dimensionality
+                     int m,            // number of query points
+                     int n,            // number of reference points
+                     float *s_points,  // queries  [m][k]
+                     float *r_points,  // refs     [n][k]
+                     int **results)    // out: malloc'd int[m], caller frees
+{
+    const int rc = nns_search_f32(k, m, n, s_points, r_points, results);
+    if (rc != NNS_OK) {
+        printf("Error: %s:%d, ", __FILE__, __LINE__);
+        printf("code:%d, reason: %s (%s) \n", rc, nns_strerror(rc), nns_last_error());
+        exit(1);
+    }
+}
+
+}  // namespace mi355x
