@@ -155,11 +155,13 @@ int nns_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset,
                      void *stream);
 
 /* Diagnostic: one 32x32 tile through the filter's MFMA k-order.  a[32][kt],
- * b[32][kt], c0[32], out[32][32] are HOST buffers; out[i][j] = the MFMA FMA chain
- * of sum_t a[i][t] * b[j][t] seeded with c0[i].  Lets a test compare the hardware's
- * v_mfma_f32_32x32x2_f32 against a host fmaf() chain (the error model behind the
- * filter's proof margin). */
-int nns_selftest_mfma(int kt, const float *a, const float *b, const float *c0, float *out);
+ * b[32][kt], c0[32], out[32][32] are HOST fp32 buffers; out[i][j] = the MFMA
+ * accumulation of sum_t a[i][t] * b[j][t] seeded with c0[i].  bf16 = 0:
+ * v_mfma_f32_32x32x2_f32 (compared by the tests with a host fmaf() chain);
+ * bf16 = 1: v_mfma_f32_32x32x16_bf16 on the values cast to bf16 (compared with
+ * fp64).  These are the error models behind the filter's proof margin tau. */
+int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const float *c0,
+                      float *out);
 
 /* ---- misc ------------------------------------------------------------------ */
 int nns_device_count(void);

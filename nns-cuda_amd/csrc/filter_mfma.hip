@@ -1,0 +1,434 @@
+// filter_mfma.hip — K3 (fp32) / K4 (bf16): the MFMA filter.  The dominant kernel.
+//
+// What the reference does here: V1/V2 write the full m x n distance matrix
+// (get_dis_kernel, core.cu:58-78) and reduce its rows (get_min_kernel core.cu:87-122 /
+// thrust::min_element core.cu:197-198); V3-V9 fuse the two but give one 1024-thread
+// block to each query and re-stream every reference point per query
+// (core.cu:589-633).  At 65536 x 1048576 x 128 the matrix would be 256 GiB.
+//
+// What this kernel does instead: the ||q - r||^2 expansion.  With x' = q - c, y' = r - c
+// (centred by K2; c = 0 on the bf16 path),
+//     s(i, j) = |y'_j|^2 - 2 x'_i . y'_j            ( = ||q_i - r_j||^2 - |x'_i|^2 )
+// has the same argmin over j.  -2 * Y' * X'^T is a dense GEMM on the matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain; v_mfma_f32_32x32x16_bf16: bf16 inputs,
+// fp32 accumulate) with |y'_j|^2 preloaded as the accumulator's initial value, so the
+// finished accumulator IS s(i, j) and the matrix never leaves the registers.
+//
+// Fused epilogue = RECORD COLLECTION, not a plain argmin: a lane keeps the running
+// minimum m1 of its query over the refs it has seen and a threshold
+// thr = m1 + tau(m1), where tau bounds |s + |x'|^2 - V0's fp32 distance| from both sides
+// (derivation in finalize.hip).  Per 32x32 tile it takes the minimum of its 16 scores
+// (8 v_min3 + 1 v_cmp); only when that beats thr (a new record or a near-record: about
+// ln(n) times per lane in total) does a wave-uniform slow path append (score, index)
+// entries to the lane's private candidate list in HBM.  Every ref whose score is within
+// tau of the query's final minimum is therefore in some list, and K5 re-ranks exactly
+// those few candidates with V0's own arithmetic: indices come out bit-identical to V0
+// although the filter itself is approximate.
+//
+// Geometry:
+//   * MFMA A = refs (rows of the 32x32 tile), B = queries (columns): the C layout puts
+//     a query on a lane (col = lane & 31) and 16 refs in the lane's 16 accumulator
+//     registers, so the running state is per lane and needs no cross-lane traffic.
+//   * a wave owns 32 queries; their B operands for all of K (64 VGPRs) are loaded once
+//     and stay resident.  A workgroup is 8 waves = 256 queries; all 8 waves consume the
+//     same stream of ref blocks from LDS (a block fetched once feeds 256 queries; the
+//     reference's V7 re-reads it per query).
+//   * refs stream through a 3-slot LDS ring (slot = 64 refs = 32 KiB of K2's tile image
+//     + 256 B of norms) filled by LDS-DMA (global_load_lds_dwordx4: the image is stored in
+//     LDS order, so the copy is linear, 1 KiB per wave-instruction), waited for with
+//     vmcnt and ONE raw s_barrier per slot; A fragments are lane-linear ds_read_b128
+//     (bank-conflict free by construction of the image).
+//   * the two waves that share a SIMD (w and w + 4) run HALF A BLOCK out of phase: waves
+//     4..7 lag by half a 32-ref block (they finish the previous slot's last half block
+//     after the barrier), so one partner's epilogue / accumulator re-seed / LDS latency
+//     falls in the middle of the other's MFMA chain instead of both stalling together
+//     at every block boundary (MI355X guide, "Two waves per SIMD", item 9).
+//   * grid = (m_pad / 256) x splits; splits > 1 only when there are fewer than 256
+//     query groups (one resident workgroup per CU).
+//
+// Roofline: MFMA-bound.  fp32: 64 MFMAs x 64 cycles per 32x32x128 tile per SIMD; bf16:
+// 16 MFMAs x 32 cycles per 32x32x256 tile.  Algorithmic HBM traffic = the images once.
+#include <stdlib.h>
+#include "nns_internal.h"
+
+namespace nns {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// compile-time unrolled loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int F_NW = 8;                  // waves per workgroup (2 per SIMD)
+constexpr int F_SB = 2;                  // 32-ref image blocks per ring slot
+constexpr int F_D = 3;                   // ring depth
+constexpr int F_QW = F_NW * 32;          // queries per workgroup
+constexpr int F_BLK_BYTES = 16384;       // one image block: 32 points x (128 fp32 | 256 bf16)
+constexpr int F_SLOT_COORD = F_SB * F_BLK_BYTES;
+constexpr int F_SLOT_BYTES = F_SLOT_COORD + F_SB * 32 * 4;
+constexpr int F_PPW = F_SLOT_COORD / 1024 / F_NW;   // 1 KiB DMA pieces per wave per slot
+constexpr int F_LDS_BYTES = F_D * F_SLOT_BYTES;
+constexpr int F_STEPS = 16;              // ds_read_b128 per lane per image block
+static_assert(F_SB * 32 == 64, "the norm piece is one dword per lane");
+
+// ---- operand traits ---------------------------------------------------------------
+struct OpF32 {   // KT = 128: float4 #b = operands of MFMA k-steps 4b .. 4b+3
+    static constexpr int kPrefetch = 2;   // fragments in flight ahead of the MFMAs (4 x 64 cycles each)
+    __device__ static __forceinline__ f32x16 mma(const float4 &a, const float4 &b, f32x16 acc)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        return acc;
+    }
+};
+struct OpBF16 {  // KT = 256: 16 bytes = 8 bf16 = one v_mfma_f32_32x32x16_bf16 operand
+    static constexpr int kPrefetch = 6;   // one MFMA (32 cycles) per fragment: deeper prefetch
+    __device__ static __forceinline__ f32x16 mma(const float4 &a, const float4 &b, f32x16 acc)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                       __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+
+// LDS-DMA (global_load_lds_*): 64 lanes x {16, 4} bytes from per-lane global addresses to
+// LDS at M0 + lane * size, no VGPR destination.  Inline asm on purpose: through the
+// builtin, hipcc (ROCm 7.2) treats every later ds_read as possibly aliasing the
+// in-flight DMA and drains it with s_waitcnt vmcnt(0) right after the issue.  The asm
+// form is invisible to that pass; completion is tracked by OUR vmcnt waits + the slot
+// barrier.  M0 is compiler-reserved: saved and restored inside the same statement.
+__device__ __forceinline__ void dma16(const void *g, unsigned lds_byte)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(lds_byte)
+                 : "memory");
+}
+__device__ __forceinline__ void dma4(const void *g, unsigned lds_byte)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(lds_byte)
+                 : "memory");
+}
+
+struct FilterArgs {
+    const float4 *qimg;     // [m_pad/32][16][64] 16-byte fragments
+    const char *rimg;       // [n_pad/32][16 KiB]
+    const float *rnorm;     // [n_pad]
+    const float *qnorm;     // [m_pad]
+    const DevScalars *scal;
+    CandEntry *lists;       // [splits][m_pad/32][kCandCap][64 lanes]
+    int *counts;            // [splits][m_pad/32][64 lanes]
+    int total_slots, slots_per_split, m_pad, kt;
+    int bf16;
+    int ablate;             // diagnostic (NNS_FILTER_ABLATE): 1 no ring sync/DMA, 2 no epilogue, 3 both
+};
+
+template <class OP>
+__global__ __launch_bounds__(F_NW * 64) void filter_kernel(const FilterArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5;
+    const int qblk = blockIdx.x * F_NW + wave;
+    const int qi = qblk * 32 + (lane & 31);
+
+    // ---- resident B operands: this wave's 32 queries, all of K (64 VGPRs) ------------
+    float4 bq[F_STEPS];
+    {
+        const float4 *src = a.qimg + (size_t)qblk * (F_STEPS * 64) + lane;
+#pragma unroll
+        for (int b = 0; b < F_STEPS; ++b) bq[b] = src[b * 64];
+    }
+    TauConsts tc = tau_consts(a.kt, a.qnorm[qi], __uint_as_float(a.scal->ymax2_bits), a.bf16 != 0);
+    // Pin the loads here: hipcc must wait for them BEFORE the ring starts, not with a
+    // vmcnt(0) at their first use inside the loop (it cannot see the asm DMAs).
+#pragma unroll
+    for (int b = 0; b < F_STEPS; ++b)
+        asm volatile("" : "+v"(bq[b].x), "+v"(bq[b].y), "+v"(bq[b].z), "+v"(bq[b].w));
+    asm volatile("" : "+v"(tc.c0), "+v"(tc.c1), "+v"(tc.x2));
+
+    const int slot0 = blockIdx.y * a.slots_per_split;
+    int ns = a.total_slots - slot0;
+    if (ns > a.slots_per_split) ns = a.slots_per_split;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+
+    auto issue = [&](int s) {   // DMA of slot s (relative to slot0) into ring position s % F_D
+        const size_t gslot = (size_t)(slot0 + s);
+        const unsigned dst = lds_base + (s % F_D) * F_SLOT_BYTES;
+        const char *src = a.rimg + gslot * F_SLOT_COORD + wave * (F_PPW * 1024) + lane * 16;
+#pragma unroll
+        for (int i = 0; i < F_PPW; ++i) dma16(src + i * 1024, dst + wave * (F_PPW * 1024) + i * 1024);
+        // the slot's 64 norms: every wave copies the same 256 B (same bytes, same words)
+        dma4(a.rnorm + gslot * 64 + lane, dst + F_SLOT_COORD);
+    };
+
+    // ---- per-lane record state ---------------------------------------------------------
+    float m1 = __builtin_inff(), thr = __builtin_inff();
+    int cnt = 0;
+    // candidate lists are stored [split][query block][entry][lane] so that both the
+    // appends of a wave and K5's per-query reads touch consecutive 8-byte words
+    const size_t lblk = (size_t)blockIdx.y * (a.m_pad / 32) + qblk;
+    CandEntry *const list = a.lists + lblk * (kCandCap * 64) + lane;
+
+    // accumulators start at |y'_j|^2 of their rows: rows (r&3) + 8(r>>2) + 4h
+    auto seed = [&](f32x16 &acc, const char *slot, int blk) {
+        const float *nrm = reinterpret_cast<const float *>(slot + F_SLOT_COORD) + blk * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 nv = *reinterpret_cast<const float4 *>(nrm + 8 * g);
+            acc[4 * g + 0] = nv.x;
+            acc[4 * g + 1] = nv.y;
+            acc[4 * g + 2] = nv.z;
+            acc[4 * g + 3] = nv.w;
+        }
+    };
+    // record collection over the 16 finished scores of one tile
+    auto epilogue = [&](const f32x16 &acc, int blk_global) {
+        if (a.ablate & 2) {
+            asm volatile("" ::"v"(acc));
+            return;
+        }
+        const float t0 = fminf(fminf(acc[0], acc[1]), acc[2]);
+        const float t1 = fminf(fminf(acc[3], acc[4]), acc[5]);
+        const float t2 = fminf(fminf(acc[6], acc[7]), acc[8]);
+        const float t3 = fminf(fminf(acc[9], acc[10]), acc[11]);
+        const float t4 = fminf(fminf(acc[12], acc[13]), acc[14]);
+        const float tm = fminf(fminf(fminf(t0, t1), acc[15]), fminf(fminf(t2, t3), t4));
+        if (__builtin_amdgcn_ballot_w64(tm <= thr) != 0ull) {   // rare: ~ln(n) tiles per lane
+            const int jbase = blk_global * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = acc[r];
+                if (x <= thr && x < __builtin_inff()) {
+                    if (cnt < kCandCap) {
+                        CandEntry e;
+                        e.s = x;
+                        e.j = jbase + (r & 3) + 8 * (r >> 2);
+                        list[cnt * 64] = e;
+                    }
+                    ++cnt;   // > kCandCap marks overflow: K5 sends the query to the exact scan
+                    if (x < m1) {
+                        m1 = x;
+                        thr = x + tau_of(tc, x) * 1.002f;   // a hair wider than K5's own tau
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- the software pipeline of one barrier interval -----------------------------------
+    // An interval is 32 fragment steps (2 image blocks x 16 fragments; one step = one
+    // ds_read_b128 + its MFMA(s)).  Waves 0..3 (LAG = 0) run blocks 0 and 1 of the current
+    // slot; waves 4..7 (LAG = 1) run half a block behind: the second half of the previous
+    // slot's block 1, all of block 0, the first half of block 1.  Even blocks accumulate
+    // in accA, odd blocks in accB, so a finished tile's epilogue is issued one step INTO
+    // the next tile's MFMA chain (its VALU work runs in the MFMA shadow) and the next
+    // tile's norms are read straight into the free accumulator well ahead of its start.
+    // Fragments are prefetched PF steps ahead through a register ring.
+    constexpr int PF = OP::kPrefetch;
+    constexpr int RING = 8;
+    static_assert(PF < RING, "prefetch ring too small");
+    f32x16 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[r] = accB[r] = __builtin_inff();
+
+    auto interval = [&](auto lag_c, const char *cur, const char *prev, int blk0_global, bool first) {
+        constexpr int LAG = decltype(lag_c)::value;
+        // compile-time schedule of step t
+        auto src_prev = [](int t) constexpr { return LAG == 1 && t < 8; };
+        auto blk_of = [](int t) constexpr { return LAG == 0 ? t / 16 : (t < 8 ? 1 : (t < 24 ? 0 : 1)); };
+        auto frag_of = [](int t) constexpr { return LAG == 0 ? t % 16 : (t < 8 ? 8 + t : (t < 24 ? t - 8 : t - 24)); };
+        constexpr int T0 = 0;
+        float4 fr[RING];
+        auto load = [&](auto tc_) {
+            constexpr int t = decltype(tc_)::value;
+            const char *base = src_prev(t) ? prev : cur;
+            fr[t % RING] = (reinterpret_cast<const float4 *>(base + blk_of(t) * F_BLK_BYTES) + lane)[frag_of(t) * 64];
+        };
+        // LAG = 1 in the very first interval has no previous slot: its steps 0..7 are skipped
+        static_for<PF>([&](auto t) {
+            if (!(LAG == 1 && decltype(t)::value < 8) || !first) load(t);
+        });
+        if (LAG == 0) seed(accA, cur, 0);                // block 0 starts this interval at once
+        static_for<32>([&](auto tc_) {
+            constexpr int t = decltype(tc_)::value;
+            constexpr int blk = blk_of(t), b = frag_of(t);
+            if constexpr (t + PF < 32) {
+                if (!(LAG == 1 && t + PF < 8) || !first) load(std::integral_constant<int, t + PF>{});
+            }
+            if constexpr (LAG == 1 && t == T0) seed(accA, cur, 0);     // used from step 8 on
+            // the other accumulator is free once its epilogue (below) has run: seed it early
+            if constexpr ((LAG == 0 && t == 4) || (LAG == 1 && t == 12)) seed(accB, cur, 1);
+            if (!(LAG == 1 && t < 8 && first)) {
+                if constexpr (blk == 0) accA = OP::mma(fr[t % RING], bq[b], accA);
+                else accB = OP::mma(fr[t % RING], bq[b], accB);
+            }
+            // deferred epilogues: one step into the following tile
+            if constexpr ((LAG == 0 && t == 1) || (LAG == 1 && t == 9)) {
+                if (!first) epilogue(accB, blk0_global - 1);            // previous slot's block 1
+            }
+            if constexpr ((LAG == 0 && t == 17) || (LAG == 1 && t == 25)) epilogue(accA, blk0_global);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    const bool lag = wave >= F_NW / 2;   // wave-uniform
+
+    if (ns > 0) issue(0);
+    for (int s = 0; s < ns; ++s) {
+        if (!(a.ablate & 1) || s == 0) {
+            // my share of slot s has landed (it is the only DMA in flight)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // everyone's share has landed; everyone is done with slot s-2
+            __builtin_amdgcn_s_barrier();
+            if (s + 1 < ns) issue(s + 1);
+        }
+        const char *cur = smem + (s % F_D) * F_SLOT_BYTES;
+        const char *prev = smem + ((s + F_D - 1) % F_D) * F_SLOT_BYTES;
+        const int blk0 = (slot0 + s) * F_SB;
+        if (!lag) interval(I0{}, cur, prev, blk0, s == 0);
+        else interval(I1{}, cur, prev, blk0, s == 0);
+    }
+    if (ns > 0) {
+        const int last_blk1 = (slot0 + ns - 1) * F_SB + 1;
+        if (lag) {   // the lagging half block of the last slot
+            const char *last = smem + ((ns - 1) % F_D) * F_SLOT_BYTES;
+            const float4 *ap = reinterpret_cast<const float4 *>(last + F_BLK_BYTES) + lane;
+#pragma unroll
+            for (int b = F_STEPS / 2; b < F_STEPS; ++b) accB = OP::mma(ap[b * 64], bq[b], accB);
+        }
+        epilogue(accB, last_blk1);
+    }
+    a.counts[lblk * 64 + lane] = cnt;
+}
+
+// ---- self-test: one 32x32 tile through the same MFMA k-order as the filter --------
+// out[i][j] = accumulate over the image's k order of a[i][.] * b[j][.] seeded with c0[i];
+// a, b are [32][kt] fp32 (bf16 mode: values must be bf16-representable).  Lets the tests
+// check the hardware against host arithmetic — the error model behind tau.
+__global__ __launch_bounds__(64) void mfma_selftest_kernel(int kt, int bf16, const float *__restrict__ a,
+                                                           const float *__restrict__ b,
+                                                           const float *__restrict__ c0,
+                                                           float *__restrict__ out)
+{
+    const int lane = threadIdx.x, h = lane >> 5, i = lane & 31;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = c0[(r & 3) + 8 * (r >> 2) + 4 * h];
+    if (!bf16) {
+        for (int s = 0; s < kt / 2; ++s) {
+            const int kk = 8 * (s >> 2) + 4 * h + (s & 3);   // same k permutation as the image
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i * kt + kk], b[i * kt + kk], acc, 0, 0, 0);
+        }
+    } else {
+        for (int s = 0; s < kt / 16; ++s) {
+            bf16x8 av, bv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                av[e] = (__bf16)a[i * kt + 16 * s + 8 * h + e];
+                bv[e] = (__bf16)b[i * kt + 16 * s + 8 * h + e];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i] = acc[r];
+}
+
+int launch_mfma_selftest(int kt, int bf16, const float *a, const float *b, const float *c0, float *out,
+                         hipStream_t st)
+{
+    hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, st, kt, bf16, a, b, c0, out);
+    NNS_HIP(hipGetLastError());
+    return NNS_OK;
+}
+
+// ---- planning + launch ---------------------------------------------------------------
+int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g)
+{
+    int kt = 0;
+    if (bf16) {
+        if (k <= 256) kt = 256;
+    } else {
+        if (k <= 128) kt = 128;
+    }
+    if (!kt) {
+        set_error("MFMA filter: k = %d exceeds the %s tile depth", k, bf16 ? "bf16 (256)" : "fp32 (128)");
+        return NNS_ERR_UNSUPPORTED;
+    }
+    g->bf16 = bf16 ? 1 : 0;
+    g->kt = kt;
+    g->m_pad = divup(m, F_QW) * F_QW;
+    const int slot_pts = 32 * F_SB;
+    g->n_pad = divup(n, slot_pts) * slot_pts;
+    g->total_slots = g->n_pad / slot_pts;
+    g->qgroups = g->m_pad / F_QW;
+    // one 8-wave workgroup is resident per CU (99 KiB of LDS): cover the 256 CUs
+    int splits = 1;
+    if (g->qgroups < 256) splits = divup(256, g->qgroups);
+    if (splits > g->total_slots) splits = g->total_slots;
+    if (splits > 65535) splits = 65535;
+    g->slots_per_split = divup(g->total_slots, splits);
+    g->splits = divup(g->total_slots, g->slots_per_split);
+    return NNS_OK;
+}
+
+template <class OP>
+static int launch_filter_t(const FilterGeom &g, const FilterArgs &args, hipStream_t st)
+{
+    auto kern = filter_kernel<OP>;
+    // > 64 KiB of dynamic LDS needs the opt-in, once per device
+    static bool attr_set[64] = {};
+    int dev = 0;
+    NNS_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        NNS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.qgroups, g.splits), dim3(F_NW * 64), F_LDS_BYTES, st, args);
+    NNS_HIP(hipGetLastError());
+    return NNS_OK;
+}
+
+int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const float *rnorm,
+                  const float *qnorm, const DevScalars *scal, CandEntry *lists, int *counts,
+                  hipStream_t st)
+{
+    FilterArgs a;
+    a.qimg = reinterpret_cast<const float4 *>(qimg);
+    a.rimg = reinterpret_cast<const char *>(rimg);
+    a.rnorm = rnorm;
+    a.qnorm = qnorm;
+    a.scal = scal;
+    a.lists = lists;
+    a.counts = counts;
+    a.total_slots = g.total_slots;
+    a.slots_per_split = g.slots_per_split;
+    a.m_pad = g.m_pad;
+    a.kt = g.kt;
+    a.bf16 = g.bf16;
+    const char *abl = getenv("NNS_FILTER_ABLATE");   // timing diagnostics only (results are wrong)
+    a.ablate = abl ? atoi(abl) : 0;
+    if (g.bf16) return launch_filter_t<OpBF16>(g, a, st);
+    return launch_filter_t<OpF32>(g, a, st);
+}
+
+}  // namespace nns

@@ -1,32 +1,34 @@
-// finalize.hip — K5: merge the filter's per-split top-2 partials, PROVE each
-// winner or hand the query to the exact scan, and emit packed (distance, index)
-// keys carrying V0's exact distance.
+// finalize.hip — K5: turn the filter's candidate lists into V0's answer.
 //
-// Role in the reference: the second-stage reductions — the LDS tree of
-// get_min_kernel (core.cu:105-119), V7's host re-rank over per-block candidates
-// (core.cu:675-696) and V8/V9's host merge over per-GPU candidates
-// (core.cu:832-852; wrong for m > 1).  Here every level reduces
-// (distance, index) pairs and the final distance is recomputed with V0's own
-// arithmetic, so keys from different splits / shards / GPUs merge with a plain
-// integer min and the result is V0's argmin bit for bit.
+// Role in the reference: the second-stage reductions — the LDS tree of get_min_kernel
+// (core.cu:105-119), V7's host re-rank over per-block candidates (core.cu:675-696) and
+// V8/V9's host merge over per-GPU candidates (core.cu:832-852; wrong for m > 1, SURVEY
+// F4).  Here the candidates are re-ranked with V0's own arithmetic on the device and the
+// result is a packed (distance, index) key, so splits / shards / GPUs merge with a plain
+// integer min and the outcome is V0's argmin bit for bit.
 //
-// The proof.  Let a <= b be the smallest and second-smallest filter score
-// s = |y'|^2 - 2 x'.y' of query i over the shard, X^2 = |x'_i|^2 and
-// Y^2 = max_j |y'_j|^2 (centred norms from K2), u = 2^-24, K = tile depth,
-// g = gamma_{K+2} = (K+2)u / (1 - (K+2)u).  For every ref j
-//     | s_j + |x'|^2 - D_j |  <=  e3 + e2,      D_j = ||q_i - r_j||^2 (real arithmetic)
-//       e3 = g (Y^2 + 2XY) + 2u Y^2     fp32 FMA chain of K steps seeded with the
-//                                        rounded norm (v_mfma_f32_32x32x2_f32 is a
-//                                        k-ordered fmaf chain; tests check that)
-//       e2 = 2.5u (X + Y)^2             the single rounding of x' = fl(x - c), y' = fl(y - c)
+// The proof.  For query i let s_j = |y'_j|^2 - 2 x'_i.y'_j be the filter score of ref j
+// (fp32 MFMA chain, or bf16 MFMA with fp32 accumulate), a = min_j s_j, X^2 = |x'_i|^2,
+// Y^2 = max_j |y'_j|^2 (K2's norms), u = 2^-24, K the tile depth, g = gamma_{K+2}.  Then for
+// every j
+//     | s_j + |x'|^2 - D_j |  <=  e3 + e2,        D_j = ||q_i - r_j||^2 in real arithmetic
+//       e3 = g (Y^2 + 2XY) + 2u Y^2    K-step FMA chain seeded with the rounded norm
+//                                       (v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain;
+//                                       tests check that on the hardware; the bf16 MFMA's
+//                                       internal order is undocumented: 2u per add assumed
+//                                       and checked against fp64 by the tests)
+//       e2 = 2.5u (X + Y)^2            the single rounding of x' = fl(x-c), y' = fl(y-c)
+//                                       (0 on the bf16 path: no centring)
 // and V0's own fp32 value d0_j (core.cu:38-43: k+1 roundings per term) satisfies
-// |d0_j - D_j| <= g D_j.  Hence if
-//     b - a  >  tau = 2 (e3 + e2) + 2 g/(1-g) (a + X^2 + e3 + e2)
-// then d0 of the filter's winner is strictly below d0 of every other ref: V0
-// would return exactly this index (ties impossible).  Otherwise the query is
-// "ambiguous" and is re-ranked by the exact scan over all refs (K1b), which IS
-// V0's arithmetic.  Either way the index is V0's.  NaN/INF/huge inputs void the
-// bound; K2's max-|value| word detects them and every query goes to the scan.
+// |d0_j - D_j| <= g D_j.  Hence with
+//     tau(a) = 2 (e3 + e2) + 2g/(1-g) (max(a + X^2, 0) + e3 + e2)
+// any ref with s_j > a + tau(a) has d0_j strictly above d0 of the filter's best ref:
+// V0's argmin lies in C_i = { j : s_j <= a + tau(a) }.  The filter appends every such j
+// to a list (its running threshold is never below a + tau(a), see filter_mfma.hip); this
+// kernel evaluates V0's exact distance for the members of C_i (1-2 refs typically) and
+// keeps the lexicographic (distance, index) minimum == V0's result, ties included.
+// Lists that overflowed, NaN/INF/huge inputs (K2's max-|value| word) or an empty list
+// send the query to the exact scan over all refs (K1b) instead.
 #include "nns_internal.h"
 
 namespace nns {
@@ -34,73 +36,84 @@ namespace nns {
 // |value| above this (or NaN/INF) voids the error analysis (squares overflow)
 constexpr unsigned kHugeBits = 0x5BB1A2BCu;   // 1e17f
 
+__device__ __forceinline__ float load_f(const float *p, size_t i) { return p[i]; }
+__device__ __forceinline__ float load_f(const uint16_t *p, size_t i)
+{
+    return __uint_as_float((unsigned)p[i] << 16);   // bf16 -> fp32 widening is exact
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void finalize_kernel(
-    int kt, int m_pad, int splits, int k, int m, int n, const float *__restrict__ q,
-    const float *__restrict__ r, const Partial *__restrict__ partials,
+    int kt, int bf16, int m_pad, int splits, int k, int m, int n, const T *__restrict__ q,
+    const T *__restrict__ r, const CandEntry *__restrict__ lists, const int *__restrict__ counts,
     const float *__restrict__ qnorm, DevScalars *__restrict__ scal, int64_t index_base,
     nns_key *__restrict__ keys, int *__restrict__ amb_list)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
 
-    float a1 = __builtin_inff(), a2 = __builtin_inff();
-    int idx = 0;
-    for (int s = 0; s < splits; ++s) {
-        const Partial p = partials[(size_t)s * m_pad + i];
-        const float hi = fmaxf(a1, p.m1);
-        if (p.m1 < a1) idx = p.idx;
-        a1 = fminf(a1, p.m1);
-        a2 = fminf(hi, fminf(a2, p.m2));
-    }
-
-    const bool bad_inputs = scal->q_maxabs_bits >= kHugeBits || scal->r_maxabs_bits >= kHugeBits;
-    bool certain = false;
-    if (!bad_inputs && a1 < __builtin_inff() && idx < n) {
-        const double u = 5.9604644775390625e-08;   // 2^-24
-        const double X2 = (double)qnorm[i] * (1.0 + 4.0 * u);
-        const double Y2 = (double)__uint_as_float(scal->ymax2_bits) * (1.0 + 4.0 * u);
-        const double X = sqrt(X2), Y = sqrt(Y2);
-        const double gk = (kt + 2) * u / (1.0 - (kt + 2) * u);
-        const double e3 = gk * (Y2 + 2.0 * X * Y) + 2.0 * u * Y2;
-        const double e2 = 2.5 * u * (X + Y) * (X + Y);
-        double ap = (double)a1 + X2;
-        if (ap < 0.0) ap = 0.0;
-        ap += e3 + e2;
-        const double tau = (2.0 * (e3 + e2) + 2.0 * gk / (1.0 - gk) * ap) * 1.001 + 1e-30;
-        certain = ((double)a2 - (double)a1) > tau;   // a2 = +INF (single ref) is certain
-    }
-
-    if (certain) {
-        // V0's exact distance of the proven winner (core.cu:38-43)
-        const float *qi = q + (size_t)i * k;
-        const float *rj = r + (size_t)idx * k;
-        float sum = 0.0f;
-        if ((k & 3) == 0 && ((((uintptr_t)q) | ((uintptr_t)r)) & 15) == 0) {
-            for (int t = 0; t < k; t += 4) {
-                const float4 qv = *reinterpret_cast<const float4 *>(qi + t);
-                const float4 rv = *reinterpret_cast<const float4 *>(rj + t);
-                sum = v0_step(sum, qv.x, rv.x);
-                sum = v0_step(sum, qv.y, rv.y);
-                sum = v0_step(sum, qv.z, rv.z);
-                sum = v0_step(sum, qv.w, rv.w);
+    bool fallback = scal->q_maxabs_bits >= kHugeBits || scal->r_maxabs_bits >= kHugeBits;
+    float a = __builtin_inff();
+    if (!fallback) {
+        for (int s = 0; s < splits; ++s)
+            for (int h = 0; h < 2; ++h) {
+                // [split][query block][entry][lane], lane = 32h + (i & 31)
+                const size_t lblk = (size_t)s * (m_pad / 32) + (i >> 5);
+                const int ln = 32 * h + (i & 31);
+                const int c = counts[lblk * 64 + ln];
+                if (c > kCandCap) fallback = true;
+                const CandEntry *l = lists + lblk * (kCandCap * 64) + ln;
+                for (int e = 0; e < c && e < kCandCap; ++e) a = fminf(a, l[e * 64].s);
             }
-        } else {
-            for (int t = 0; t < k; ++t) sum = v0_step(sum, qi[t], rj[t]);
-        }
-        keys[i] = make_key(sum, index_base + idx);
-    } else {
+    }
+    if (!(a < __builtin_inff())) fallback = true;
+
+    nns_key best = NNS_KEY_NONE;
+    if (!fallback) {
+        const TauConsts tc = tau_consts(kt, qnorm[i], __uint_as_float(scal->ymax2_bits), bf16 != 0);
+        const float thr = a + tau_of(tc, a);
+        const T *qi = q + (size_t)i * k;
+        for (int s = 0; s < splits; ++s)
+            for (int h = 0; h < 2; ++h) {
+                const size_t lblk = (size_t)s * (m_pad / 32) + (i >> 5);
+                const int ln = 32 * h + (i & 31);
+                const int c = counts[lblk * 64 + ln];
+                const CandEntry *l = lists + lblk * (kCandCap * 64) + ln;
+                for (int e = 0; e < c; ++e) {
+                    const CandEntry ce = l[e * 64];
+                    if (ce.s <= thr && ce.j < n) {
+                        // V0's exact distance (core.cu:38-43) of candidate ce.j
+                        const T *rj = r + (size_t)ce.j * k;
+                        float sum = 0.0f;
+                        for (int t = 0; t < k; ++t) sum = v0_step(sum, load_f(qi, t), load_f(rj, t));
+                        const nns_key key = make_key(sum, index_base + ce.j);
+                        best = key < best ? key : best;
+                    }
+                }
+            }
+        // every candidate NaN/INF cannot happen with bounded inputs; be safe anyway
+        if (best == NNS_KEY_NONE) fallback = true;
+    }
+    keys[i] = best;
+    if (fallback) {
         keys[i] = NNS_KEY_NONE;
         const int pos = atomicAdd(&scal->amb_count, 1);
         amb_list[pos] = i;
     }
 }
 
-int launch_finalize(const FilterGeom &g, int k, int m, int n, const float *q, const float *r,
-                    const Partial *partials, const float *qnorm, DevScalars *scal,
+int launch_finalize(const FilterGeom &g, int k, int m, int n, const void *q, const void *r,
+                    const CandEntry *lists, const int *counts, const float *qnorm, DevScalars *scal,
                     int64_t index_base, nns_key *keys, int *amb_list, hipStream_t st)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3(divup(m, 256)), dim3(256), 0, st, g.kt, g.m_pad,
-                       g.splits, k, m, n, q, r, partials, qnorm, scal, index_base, keys, amb_list);
+    if (g.bf16)
+        hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(divup(m, 256)), dim3(256), 0, st, g.kt, 1, g.m_pad,
+                           g.splits, k, m, n, (const uint16_t *)q, (const uint16_t *)r, lists, counts, qnorm,
+                           scal, index_base, keys, amb_list);
+    else
+        hipLaunchKernelGGL(finalize_kernel<float>, dim3(divup(m, 256)), dim3(256), 0, st, g.kt, 0, g.m_pad,
+                           g.splits, k, m, n, (const float *)q, (const float *)r, lists, counts, qnorm, scal,
+                           index_base, keys, amb_list);
     NNS_HIP(hipGetLastError());
     return NNS_OK;
 }

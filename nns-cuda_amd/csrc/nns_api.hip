@@ -49,8 +49,9 @@ struct nns_index {
     // MFMA path, query side (grown on demand)
     int m_cap = 0;
     float *qimg = nullptr, *qnorm = nullptr;
-    Partial *partials = nullptr;
-    size_t partials_cap = 0;
+    CandEntry *lists = nullptr;   // [splits][m_pad/32][kCandCap][64]
+    int *counts = nullptr;        // [splits][m_pad/32][64]
+    size_t lists_cap = 0;         // in lane-lists
     int *amb_list = nullptr;
 
     hipEvent_t ev[EV_COUNT] = {};
@@ -123,7 +124,8 @@ int nns_index_destroy(nns_index *ix)
     hipFree(ix->scal);
     hipFree(ix->qimg);
     hipFree(ix->qnorm);
-    hipFree(ix->partials);
+    hipFree(ix->lists);
+    hipFree(ix->counts);
     hipFree(ix->amb_list);
     if (ix->ev_valid)
         for (int i = 0; i < EV_COUNT; ++i) hipEventDestroy(ix->ev[i]);
@@ -178,7 +180,7 @@ int nns_index_create(nns_index **out, int device, int k, int n, const float *r_d
             ix->ev_valid = true;
         }
         if (path == NNS_PATH_MFMA) {
-            if ((rc = filter_plan(k, 1, n, &ix->geom)) != NNS_OK) break;
+            if ((rc = filter_plan(k, 1, n, false, &ix->geom)) != NNS_OK) break;
             const FilterGeom &g = ix->geom;
             size_t ws = 0;
             prep_workspace_bytes(g.kt, &ws);
@@ -229,7 +231,7 @@ static int ensure_query_ws(nns_index *ix, int m)
 {
     FilterGeom g = ix->geom;
     FilterGeom gq{};
-    NNS_TRY(filter_plan(ix->k, m, ix->n, &gq));
+    NNS_TRY(filter_plan(ix->k, m, ix->n, false, &gq));
     ix->geom = gq;   // same kt / n_pad / total_slots; m-dependent grid now filled in
     (void)g;
     if (gq.m_pad > ix->m_cap) {
@@ -248,16 +250,19 @@ static int ensure_query_ws(nns_index *ix, int m)
         }
         ix->m_cap = gq.m_pad;
     }
-    const size_t need = (size_t)gq.splits * gq.m_pad;
-    if (need > ix->partials_cap) {
-        hipFree(ix->partials);
-        ix->partials = nullptr;
-        ix->partials_cap = 0;
-        if (hipMalloc(&ix->partials, need * sizeof(Partial)) != hipSuccess) {
-            set_error("partials allocation failed (%zu entries)", need);
+    const size_t need = (size_t)gq.splits * gq.m_pad * 2;   // lane-lists
+    if (need > ix->lists_cap) {
+        hipFree(ix->lists);
+        hipFree(ix->counts);
+        ix->lists = nullptr;
+        ix->counts = nullptr;
+        ix->lists_cap = 0;
+        if (hipMalloc(&ix->lists, need * kCandCap * sizeof(CandEntry)) != hipSuccess ||
+            hipMalloc(&ix->counts, need * sizeof(int)) != hipSuccess) {
+            set_error("candidate list allocation failed (%zu lists)", need);
             return NNS_ERR_NOMEM;
         }
-        ix->partials_cap = need;
+        ix->lists_cap = need;
     }
     return NNS_OK;
 }
@@ -291,10 +296,10 @@ int nns_index_search(nns_index *ix, int m, const float *q_dev, nns_key *keys_dev
     NNS_TRY(launch_prep_image(ix->k, g.kt, m, g.m_pad, q_dev, ix->mean, 1.0f, 0.0f, ix->qimg,
                               ix->qnorm, nullptr, &ix->scal->q_maxabs_bits, st));
     if (prof) hipEventRecord(ix->ev[EV_QPREP], st);
-    NNS_TRY(launch_filter_f32(g, ix->qimg, ix->rimg, ix->rnorm, ix->partials, st));
+    NNS_TRY(launch_filter(g, ix->qimg, ix->rimg, ix->rnorm, ix->qnorm, ix->scal, ix->lists, ix->counts, st));
     if (prof) hipEventRecord(ix->ev[EV_FILTER], st);
-    NNS_TRY(launch_finalize(g, ix->k, m, ix->n, q_dev, ix->r_dev, ix->partials, ix->qnorm, ix->scal,
-                            ix->base, keys_dev, ix->amb_list, st));
+    NNS_TRY(launch_finalize(g, ix->k, m, ix->n, q_dev, ix->r_dev, ix->lists, ix->counts, ix->qnorm,
+                            ix->scal, ix->base, keys_dev, ix->amb_list, st));
     if (prof) hipEventRecord(ix->ev[EV_FINAL], st);
     NNS_TRY(launch_exact_listed(ix->k, ix->n, q_dev, ix->r_dev, ix->amb_list, &ix->scal->amb_count,
                                 m, ix->base, keys_dev, st));
@@ -362,9 +367,9 @@ int nns_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset, v
     return launch_fill_uniform(dev, count, seed, offset, (hipStream_t)stream);
 }
 
-int nns_selftest_mfma(int kt, const float *a, const float *b, const float *c0, float *out)
+int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const float *c0, float *out)
 {
-    if (kt <= 0 || (kt & 7) || !a || !b || !c0 || !out) return NNS_ERR_INVALID;
+    if (kt <= 0 || (kt & 15) || !a || !b || !c0 || !out) return NNS_ERR_INVALID;
     NNS_TRY(ensure_device_ok(0));
     float *d = nullptr;
     const size_t na = (size_t)32 * kt, total = 2 * na + 32 + 1024;
@@ -374,7 +379,7 @@ int nns_selftest_mfma(int kt, const float *a, const float *b, const float *c0, f
         hipMemcpy(d + na, b, na * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d + 2 * na, c0, 32 * 4, hipMemcpyHostToDevice) != hipSuccess)
         rc = NNS_ERR_HIP;
-    if (rc == NNS_OK) rc = launch_mfma_selftest(kt, d, d + na, d + 2 * na, d + 2 * na + 32, nullptr);
+    if (rc == NNS_OK) rc = launch_mfma_selftest(kt, bf16, d, d + na, d + 2 * na, d + 2 * na + 32, nullptr);
     if (rc == NNS_OK && hipMemcpy(out, d + 2 * na + 32, 1024 * 4, hipMemcpyDeviceToHost) != hipSuccess)
         rc = NNS_ERR_HIP;
     if (rc == NNS_ERR_HIP) set_error("nns_selftest_mfma: %s", hipGetErrorString(hipGetLastError()));

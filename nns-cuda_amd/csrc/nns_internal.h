@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <math.h>
+#include <type_traits>
 #include "nns.h"
 
 namespace nns {
@@ -63,7 +65,7 @@ __device__ __forceinline__ float v0_step(float sum, float q, float r)
 constexpr int kBlockPts = 32;
 
 struct FilterGeom {
-    int variant;          // filter kernel configuration (filter_f32.hip)
+    int bf16;             // 1: bf16 operands (K4), 0: fp32 operands (K3)
     int kt;               // K of the tile (k padded up with zeros)
     int m_pad;            // queries padded to the workgroup's query count
     int n_pad;            // refs padded to a whole ring slot
@@ -73,13 +75,56 @@ struct FilterGeom {
     int qgroups;          // grid.x
 };
 
-// filter partial result per (split, query): top-2 of s = |r'|^2 - 2 q'.r'
-struct __attribute__((aligned(16))) Partial {
-    float m1;  // smallest score
-    float m2;  // second smallest score (over everything else this split saw)
-    int idx;   // shard-local ref index of m1
-    int pad;
+// One candidate of the filter: score s = |y'|^2 - 2 x'.y' and shard-local ref index.
+struct __attribute__((aligned(8))) CandEntry {
+    float s;
+    int j;
 };
+// capacity of one lane's private candidate list (per split, query, lane half); a lane
+// collects ~ln(refs it sees) records, so 32 overflows only on adversarial inputs — an
+// overflowing query is re-ranked by the exact scan instead.
+constexpr int kCandCap = 32;
+
+// tau(a) = c0 + c1 * max(a + x2, 0): the margin within which a filter score cannot be
+// ordered against V0's fp32 distances (derivation: finalize.hip).  Shared by K3/K4 (which
+// widen it by 0.2 % so their candidate sets are supersets) and K5.
+struct TauConsts {
+    float c0, c1, x2;
+};
+
+__host__ __device__ inline TauConsts tau_consts(int kt, float qnorm2, float ymax2, bool bf16)
+{
+    const double u = 5.9604644775390625e-08;   // 2^-24
+    const double X2 = (double)qnorm2 * (1.0 + 4.0 * u);
+    const double Y2 = (double)ymax2 * (1.0 + 4.0 * u);
+    const double X = sqrt(X2), Y = sqrt(Y2);
+    const double gk = (kt + 2) * u / (1.0 - (kt + 2) * u);   // V0's own rounding (k+1 per term)
+    double e3, e2;
+    if (!bf16) {
+        // fp32 MFMA = k-ordered fmaf chain of kt steps seeded with the rounded norm
+        e3 = gk * (Y2 + 2.0 * X * Y) + 2.0 * u * Y2;
+        e2 = 2.5 * u * (X + Y) * (X + Y);   // x' = fl(x - c), y' = fl(y - c)
+    } else {
+        // bf16 products are exact in fp32; the accumulation order/rounding inside
+        // v_mfma_f32_32x32x16_bf16 is not documented: allow 2u per add, kt + kt/16 adds
+        const double gf = 2.0 * (kt + kt / 16 + 2) * u / (1.0 - 2.0 * (kt + kt / 16 + 2) * u);
+        e3 = gf * (Y2 + 2.0 * X * Y) + 2.0 * u * Y2;
+        e2 = 0.0;                            // no centring on the bf16 path
+    }
+    const double c1 = 2.0 * gk / (1.0 - gk) * 1.001;
+    const double c0 = (2.0 + c1) * (e3 + e2) * 1.001 + 1e-30;
+    TauConsts t;
+    t.c0 = (float)(c0 * (1.0 + 1e-6));
+    t.c1 = (float)(c1 * (1.0 + 1e-6));
+    t.x2 = (float)(X2 * (1.0 + 1e-6));
+    return t;
+}
+
+__host__ __device__ inline float tau_of(const TauConsts &t, float a)
+{
+    const float d = a + t.x2;
+    return t.c0 + t.c1 * (d > 0.0f ? d : 0.0f);
+}
 
 // device-side scalars shared between kernels of one index
 struct DevScalars {
@@ -114,18 +159,18 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts,
                       float *img, float *norms, unsigned *max_norm_bits,
                       unsigned *maxabs_bits, hipStream_t st);
 
-// filter_f32.hip (K3)
-int filter_plan(int k, int m, int n, FilterGeom *g);
-int launch_filter_f32(const FilterGeom &g, const float *qimg, const float *rimg,
-                      const float *rnorm, Partial *partials, hipStream_t st);
-
-int launch_mfma_selftest(int kt, const float *a, const float *b, const float *c0, float *out,
+// filter_mfma.hip (K3 fp32 / K4 bf16)
+int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g);
+int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const float *rnorm,
+                  const float *qnorm, const DevScalars *scal, CandEntry *lists, int *counts,
+                  hipStream_t st);
+int launch_mfma_selftest(int kt, int bf16, const float *a, const float *b, const float *c0, float *out,
                          hipStream_t st);
 
 // finalize.hip (K5)
-int launch_finalize(const FilterGeom &g, int k, int m, int n, const float *q,
-                    const float *r, const Partial *partials, const float *qnorm,
-                    DevScalars *scal, int64_t index_base, nns_key *keys,
-                    int *amb_list, hipStream_t st);
+int launch_finalize(const FilterGeom &g, int k, int m, int n, const void *q, const void *r,
+                    const CandEntry *lists, const int *counts, const float *qnorm,
+                    DevScalars *scal, int64_t index_base, nns_key *keys, int *amb_list,
+                    hipStream_t st);
 
 }  // namespace nns

@@ -86,7 +86,7 @@ def _load() -> ctypes.CDLL:
     lib.nns_keys_min.argtypes = [c_vp, c_vp, c_int, c_vp]
     lib.nns_keys_unpack.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
     lib.nns_fill_uniform.argtypes = [c_vp, c_sz, c_u64, c_u64, c_vp]
-    lib.nns_selftest_mfma.argtypes = [c_int, c_vp, c_vp, c_vp, c_vp]
+    lib.nns_selftest_mfma.argtypes = [c_int, c_int, c_vp, c_vp, c_vp, c_vp]
     lib.nns_device_count.argtypes = []
     lib.nns_strerror.argtypes = [c_int]
     lib.nns_strerror.restype = ctypes.c_char_p
@@ -110,14 +110,14 @@ def _check(status: int, where: str) -> None:
         raise NNSError(status, where, detail)
 
 
-def selftest_mfma(a: np.ndarray, b: np.ndarray, c0: np.ndarray) -> np.ndarray:
+def selftest_mfma(a: np.ndarray, b: np.ndarray, c0: np.ndarray, bf16: bool = False) -> np.ndarray:
     """out[i][j] of one 32x32 MFMA tile (diagnostic, see include/nns.h)."""
     a = np.ascontiguousarray(a, np.float32)
     b = np.ascontiguousarray(b, np.float32)
     c0 = np.ascontiguousarray(c0, np.float32)
     assert a.shape == b.shape and a.shape[0] == 32 and c0.shape == (32,)
     out = np.empty((32, 32), np.float32)
-    _check(lib.nns_selftest_mfma(a.shape[1], a.ctypes.data, b.ctypes.data, c0.ctypes.data, out.ctypes.data),
+    _check(lib.nns_selftest_mfma(a.shape[1], int(bf16), a.ctypes.data, b.ctypes.data, c0.ctypes.data, out.ctypes.data),
            "nns_selftest_mfma")
     return out
 
