@@ -139,6 +139,20 @@ int nns_index_refresh(nns_index *ix, void *stream);
 int nns_index_search(nns_index *ix, int m, const float *q_dev,
                      nns_key *keys_dev, void *stream);
 
+/* bf16 points (config C5: bf16 inputs, fp32 accumulate).  Arrays hold raw bf16 bit
+ * patterns (uint16_t), same [points][k] layout.  Semantics: V0's arithmetic on the
+ * bf16 values widened to fp32 (the reference has no bf16 code; SURVEY 8c defines the
+ * oracle this way).  MFMA filter for 32 <= k <= 256 (v_mfma_f32_32x32x16_bf16), exact
+ * kernels otherwise.  An index and its queries must have the same dtype. */
+int nns_index_create_bf16(nns_index **out, int device, int k, int n,
+                          const uint16_t *r_dev, int64_t index_base,
+                          unsigned flags, void *stream);
+int nns_index_search_bf16(nns_index *ix, int m, const uint16_t *q_dev,
+                          nns_key *keys_dev, void *stream);
+int nns_search_bf16_ex(int k, int m, int n, const uint16_t *s_points,
+                       const uint16_t *r_points, int *idx_out, float *dist_out,
+                       int num_shards, unsigned flags, int device);
+
 int nns_index_stats(nns_index *ix, nns_stats *out);
 
 /* inout[i] = min(inout[i], other[i]) : the cross-shard merge operator. */

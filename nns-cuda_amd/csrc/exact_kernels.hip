@@ -210,9 +210,24 @@ static int launch_k1a(int m, int n, const float *q, const float *r, int64_t base
 // ---------------------------------------------------------------------------
 // K1b: lane = ref, query tile in LDS (broadcast reads)
 // ---------------------------------------------------------------------------
-template <int QT, int VEC>
+// element access: fp32 as is; bf16 (raw uint16 bits) widened exactly to fp32
+__device__ __forceinline__ float ld1(const float *p) { return *p; }
+__device__ __forceinline__ float ld1(const uint16_t *p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 ld4(const uint16_t *p)
+{
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);   // 4 bf16
+    float4 o;
+    o.x = __uint_as_float(v.x << 16);
+    o.y = __uint_as_float(v.x & 0xFFFF0000u);
+    o.z = __uint_as_float(v.y << 16);
+    o.w = __uint_as_float(v.y & 0xFFFF0000u);
+    return o;
+}
+
+template <int QT, int VEC, typename T>
 __global__ __launch_bounds__(256) void exact_lane_ref_kernel(
-    int k, int n, const float *__restrict__ q, const float *__restrict__ r,
+    int k, int n, const T *__restrict__ q, const T *__restrict__ r,
     const int *__restrict__ qlist, const int *__restrict__ qcount, int mq,
     int64_t index_base, nns_key *__restrict__ keys)
 {
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(256) void exact_lane_ref_kernel(
             float v = 0.0f;
             if (qslot < nq) {
                 const int qi = qlist ? qlist[qslot] : qslot;
-                v = q[(size_t)qi * k + t];
+                v = ld1(q + (size_t)qi * k + t);
             }
             sq[e] = v;
         }
@@ -243,13 +258,13 @@ __global__ __launch_bounds__(256) void exact_lane_ref_kernel(
             bidx[u] = 0;
         }
         for (int j = blockIdx.x * 256 + tid; j < n; j += gridDim.x * 256) {
-            const float *rj = r + (size_t)j * k;
+            const T *rj = r + (size_t)j * k;
             float sum[QT];
 #pragma unroll
             for (int u = 0; u < QT; ++u) sum[u] = 0.0f;
             if (VEC == 4) {
                 for (int t = 0; t < k; t += 4) {
-                    const float4 rv = *reinterpret_cast<const float4 *>(rj + t);
+                    const float4 rv = ld4(rj + t);
 #pragma unroll
                     for (int u = 0; u < QT; ++u) {
                         const float4 qv = *reinterpret_cast<const float4 *>(&sq[u * k + t]);
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(256) void exact_lane_ref_kernel(
                 }
             } else {
                 for (int t = 0; t < k; ++t) {
-                    const float rv = rj[t];
+                    const float rv = ld1(rj + t);
 #pragma unroll
                     for (int u = 0; u < QT; ++u) sum[u] = v0_step(sum[u], sq[u * k + t], rv);
                 }
@@ -295,12 +310,12 @@ __global__ __launch_bounds__(256) void exact_lane_ref_kernel(
     }
 }
 
-template <int QT>
-static int launch_k1b_t(int k, int n, const float *q, const float *r, const int *qlist,
+template <int QT, typename T>
+static int launch_k1b_t(int k, int n, const T *q, const T *r, const int *qlist,
                         const int *qcount, int mq, int groups, int64_t base, nns_key *keys,
                         hipStream_t st)
 {
-    const bool vec = (k % 4 == 0) && (((uintptr_t)r & 15) == 0);
+    const bool vec = (k % 4 == 0) && (((uintptr_t)r & (4 * sizeof(T) - 1)) == 0);
     const size_t lds = (size_t)QT * k * sizeof(float);
     int xblocks = divup(n, 256);
     // about 8 workgroups per CU in total; refs are strided over gridDim.x
@@ -309,12 +324,12 @@ static int launch_k1b_t(int k, int n, const float *q, const float *r, const int 
     if (xblocks > target) xblocks = target;
     dim3 grid(xblocks, groups);
     if (vec) {
-        auto kern = exact_lane_ref_kernel<QT, 4>;
+        auto kern = exact_lane_ref_kernel<QT, 4, T>;
         if (lds > 48 * 1024)
             NNS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k, n, q, r, qlist, qcount, mq, base, keys);
     } else {
-        auto kern = exact_lane_ref_kernel<QT, 1>;
+        auto kern = exact_lane_ref_kernel<QT, 1, T>;
         if (lds > 48 * 1024)
             NNS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k, n, q, r, qlist, qcount, mq, base, keys);
@@ -334,15 +349,16 @@ static int pick_qt(int k, int nq)
     return qt >= 4 ? 4 : 1;
 }
 
-static int launch_k1b(int k, int n, const float *q, const float *r, const int *qlist,
+template <typename T>
+static int launch_k1b(int k, int n, const T *q, const T *r, const int *qlist,
                       const int *qcount, int mq, int qt, int groups, int64_t base,
                       nns_key *keys, hipStream_t st)
 {
     switch (qt) {
-    case 32: return launch_k1b_t<32>(k, n, q, r, qlist, qcount, mq, groups, base, keys, st);
-    case 8: return launch_k1b_t<8>(k, n, q, r, qlist, qcount, mq, groups, base, keys, st);
-    case 4: return launch_k1b_t<4>(k, n, q, r, qlist, qcount, mq, groups, base, keys, st);
-    default: return launch_k1b_t<1>(k, n, q, r, qlist, qcount, mq, groups, base, keys, st);
+    case 32: return launch_k1b_t<32, T>(k, n, q, r, qlist, qcount, mq, groups, base, keys, st);
+    case 8: return launch_k1b_t<8, T>(k, n, q, r, qlist, qcount, mq, groups, base, keys, st);
+    case 4: return launch_k1b_t<4, T>(k, n, q, r, qlist, qcount, mq, groups, base, keys, st);
+    default: return launch_k1b_t<1, T>(k, n, q, r, qlist, qcount, mq, groups, base, keys, st);
     }
 }
 
@@ -375,7 +391,30 @@ int launch_exact_search(int k, int m, int n, const float *q, const float *r,
     const int qt = pick_qt(k, m);
     int groups = divup(m, qt);
     if (groups > 4096) groups = 4096;   // grid.y strides over the rest
-    return launch_k1b(k, n, q, r, nullptr, nullptr, m, qt, groups, index_base, keys, st);
+    return launch_k1b<float>(k, n, q, r, nullptr, nullptr, m, qt, groups, index_base, keys, st);
+}
+
+int launch_exact_search_bf16(int k, int m, int n, const uint16_t *q, const uint16_t *r,
+                             int64_t index_base, nns_key *keys, hipStream_t st)
+{
+    NNS_TRY(check_k(k));
+    NNS_TRY(launch_keys_fill(keys, m, NNS_KEY_NONE, st));
+    const int qt = pick_qt(k, m);
+    int groups = divup(m, qt);
+    if (groups > 4096) groups = 4096;
+    return launch_k1b<uint16_t>(k, n, q, r, nullptr, nullptr, m, qt, groups, index_base, keys, st);
+}
+
+int launch_exact_listed_bf16(int k, int n, const uint16_t *q, const uint16_t *r, const int *qlist,
+                             const int *qcount, int max_listed, int64_t index_base, nns_key *keys,
+                             hipStream_t st)
+{
+    if (max_listed <= 0) return NNS_OK;
+    NNS_TRY(check_k(k));
+    const int qt = pick_qt(k, max_listed >= 32 ? 32 : max_listed);
+    int groups = divup(max_listed, qt);
+    if (groups > 8) groups = 8;
+    return launch_k1b<uint16_t>(k, n, q, r, qlist, qcount, 0, qt, groups, index_base, keys, st);
 }
 
 int launch_exact_listed(int k, int n, const float *q, const float *r, const int *qlist,
@@ -391,7 +430,7 @@ int launch_exact_listed(int k, int n, const float *q, const float *r, const int 
     const int qt = pick_qt(k, max_listed >= 32 ? 32 : max_listed);
     int groups = divup(max_listed, qt);
     if (groups > 8) groups = 8;
-    return launch_k1b(k, n, q, r, qlist, qcount, 0, qt, groups, index_base, keys, st);
+    return launch_k1b<float>(k, n, q, r, qlist, qcount, 0, qt, groups, index_base, keys, st);
 }
 
 }  // namespace nns

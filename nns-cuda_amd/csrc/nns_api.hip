@@ -28,6 +28,9 @@ void set_error(const char *fmt, ...)
 
 using namespace nns;
 
+// one point of either tile image is 512 bytes: 128 fp32 dims or 256 bf16 dims
+static const size_t F_IMG_ROW_BYTES = 512;
+
 enum { EV_BEGIN = 0, EV_QPREP, EV_FILTER, EV_FINAL, EV_RERANK, EV_END, EV_R0, EV_R1, EV_COUNT };
 
 struct nns_index {
@@ -36,19 +39,22 @@ struct nns_index {
     int64_t base = 0;
     unsigned flags = 0;
     int path = NNS_PATH_EXACT;
-    const float *r_dev = nullptr;
+    const void *r_dev = nullptr;   // fp32 [n][k] or bf16 bits [n][k]
+    int bf16 = 0;
     bool profile = false;
     bool refs_bad = false;
 
     // MFMA path, ref side
     FilterGeom geom{};
-    float *rimg = nullptr, *rnorm = nullptr, *mean = nullptr;
+    void *rimg = nullptr;
+    float *rnorm = nullptr, *mean = nullptr;
     double *mean_ws = nullptr;
     DevScalars *scal = nullptr;
 
     // MFMA path, query side (grown on demand)
     int m_cap = 0;
-    float *qimg = nullptr, *qnorm = nullptr;
+    void *qimg = nullptr;
+    float *qnorm = nullptr;
     CandEntry *lists = nullptr;   // [splits][m_pad/32][kCandCap][64]
     int *counts = nullptr;        // [splits][m_pad/32][64]
     size_t lists_cap = 0;         // in lane-lists
@@ -80,10 +86,16 @@ static int prep_refs(nns_index *ix, hipStream_t st)
 {
     const FilterGeom &g = ix->geom;
     NNS_HIP(hipMemsetAsync(ix->scal, 0, sizeof(DevScalars), st));
-    NNS_TRY(launch_prep_mean(ix->k, g.kt, ix->n, ix->r_dev, ix->mean_ws, ix->mean,
+    if (ix->bf16) {
+        NNS_TRY(launch_prep_image_bf16(ix->k, ix->n, g.n_pad, (const uint16_t *)ix->r_dev, -2.0f, INFINITY,
+                                       ix->rimg, ix->rnorm, &ix->scal->ymax2_bits,
+                                       &ix->scal->r_maxabs_bits, st));
+        return NNS_OK;
+    }
+    NNS_TRY(launch_prep_mean(ix->k, g.kt, ix->n, (const float *)ix->r_dev, ix->mean_ws, ix->mean,
                              &ix->scal->r_maxabs_bits, st));
-    NNS_TRY(launch_prep_image(ix->k, g.kt, ix->n, g.n_pad, ix->r_dev, ix->mean, -2.0f,
-                              INFINITY, ix->rimg, ix->rnorm, &ix->scal->ymax2_bits, nullptr, st));
+    NNS_TRY(launch_prep_image(ix->k, g.kt, ix->n, g.n_pad, (const float *)ix->r_dev, ix->mean, -2.0f,
+                              INFINITY, (float *)ix->rimg, ix->rnorm, &ix->scal->ymax2_bits, nullptr, st));
     return NNS_OK;
 }
 
@@ -133,8 +145,8 @@ int nns_index_destroy(nns_index *ix)
     return NNS_OK;
 }
 
-int nns_index_create(nns_index **out, int device, int k, int n, const float *r_dev,
-                     int64_t index_base, unsigned flags, void *stream)
+static int index_create_impl(nns_index **out, int device, int k, int n, const void *r_dev, int bf16,
+                             int64_t index_base, unsigned flags, void *stream)
 {
     if (!out || !r_dev || k <= 0 || n <= 0) {
         set_error("nns_index_create: k, n must be > 0 and pointers non-null (k=%d n=%d)", k, n);
@@ -156,12 +168,14 @@ int nns_index_create(nns_index **out, int device, int k, int n, const float *r_d
     ix->base = index_base;
     ix->flags = flags;
     ix->r_dev = r_dev;
+    ix->bf16 = bf16;
     ix->profile = (flags & NNS_PROFILE) != 0;
 
+    const int kmax = bf16 ? 256 : 128;   // tile depth of the MFMA filter
     int path = flags & NNS_PATH_MASK;
-    if (path == NNS_PATH_AUTO) path = (k >= 32 && k <= 128) ? NNS_PATH_MFMA : NNS_PATH_EXACT;
-    if (path == NNS_PATH_MFMA && k > 128) {
-        set_error("NNS_PATH_MFMA: k = %d > 128 is not tiled yet (use NNS_PATH_AUTO/EXACT)", k);
+    if (path == NNS_PATH_AUTO) path = (k >= 32 && k <= kmax) ? NNS_PATH_MFMA : NNS_PATH_EXACT;
+    if (path == NNS_PATH_MFMA && k > kmax) {
+        set_error("NNS_PATH_MFMA: k = %d > %d is not tiled yet (use NNS_PATH_AUTO/EXACT)", k, kmax);
         delete ix;
         return NNS_ERR_UNSUPPORTED;
     }
@@ -180,11 +194,11 @@ int nns_index_create(nns_index **out, int device, int k, int n, const float *r_d
             ix->ev_valid = true;
         }
         if (path == NNS_PATH_MFMA) {
-            if ((rc = filter_plan(k, 1, n, false, &ix->geom)) != NNS_OK) break;
+            if ((rc = filter_plan(k, 1, n, bf16 != 0, &ix->geom)) != NNS_OK) break;
             const FilterGeom &g = ix->geom;
             size_t ws = 0;
             prep_workspace_bytes(g.kt, &ws);
-            if (hipMalloc(&ix->rimg, (size_t)g.n_pad * g.kt * sizeof(float)) != hipSuccess ||
+            if (hipMalloc(&ix->rimg, (size_t)g.n_pad * (F_IMG_ROW_BYTES)) != hipSuccess ||
                 hipMalloc(&ix->rnorm, (size_t)g.n_pad * sizeof(float)) != hipSuccess ||
                 hipMalloc(&ix->mean, (size_t)g.kt * sizeof(float)) != hipSuccess ||
                 hipMalloc(&ix->mean_ws, ws) != hipSuccess ||
@@ -215,6 +229,18 @@ int nns_index_create(nns_index **out, int device, int k, int n, const float *r_d
     return NNS_OK;
 }
 
+int nns_index_create(nns_index **out, int device, int k, int n, const float *r_dev, int64_t index_base,
+                     unsigned flags, void *stream)
+{
+    return index_create_impl(out, device, k, n, r_dev, 0, index_base, flags, stream);
+}
+
+int nns_index_create_bf16(nns_index **out, int device, int k, int n, const uint16_t *r_dev,
+                          int64_t index_base, unsigned flags, void *stream)
+{
+    return index_create_impl(out, device, k, n, r_dev, 1, index_base, flags, stream);
+}
+
 int nns_index_refresh(nns_index *ix, void *stream)
 {
     if (!ix) return NNS_ERR_INVALID;
@@ -231,7 +257,7 @@ static int ensure_query_ws(nns_index *ix, int m)
 {
     FilterGeom g = ix->geom;
     FilterGeom gq{};
-    NNS_TRY(filter_plan(ix->k, m, ix->n, false, &gq));
+    NNS_TRY(filter_plan(ix->k, m, ix->n, ix->bf16 != 0, &gq));
     ix->geom = gq;   // same kt / n_pad / total_slots; m-dependent grid now filled in
     (void)g;
     if (gq.m_pad > ix->m_cap) {
@@ -242,7 +268,7 @@ static int ensure_query_ws(nns_index *ix, int m)
         ix->qnorm = nullptr;
         ix->amb_list = nullptr;
         ix->m_cap = 0;
-        if (hipMalloc(&ix->qimg, (size_t)gq.m_pad * gq.kt * sizeof(float)) != hipSuccess ||
+        if (hipMalloc(&ix->qimg, (size_t)gq.m_pad * (F_IMG_ROW_BYTES)) != hipSuccess ||
             hipMalloc(&ix->qnorm, (size_t)gq.m_pad * sizeof(float)) != hipSuccess ||
             hipMalloc(&ix->amb_list, (size_t)gq.m_pad * sizeof(int)) != hipSuccess) {
             set_error("query workspace allocation failed (m_pad=%d)", gq.m_pad);
@@ -267,8 +293,12 @@ static int ensure_query_ws(nns_index *ix, int m)
     return NNS_OK;
 }
 
-int nns_index_search(nns_index *ix, int m, const float *q_dev, nns_key *keys_dev, void *stream)
+static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, nns_key *keys_dev, void *stream)
 {
+    if (ix && ix->bf16 != bf16) {
+        set_error("nns_index_search: query dtype does not match the index (%s index)", ix->bf16 ? "bf16" : "fp32");
+        return NNS_ERR_INVALID;
+    }
     if (!ix || !q_dev || !keys_dev || m <= 0) {
         set_error("nns_index_search: m must be > 0 and pointers non-null (m=%d)", m);
         return NNS_ERR_INVALID;
@@ -280,7 +310,12 @@ int nns_index_search(nns_index *ix, int m, const float *q_dev, nns_key *keys_dev
 
     if (ix->path != NNS_PATH_MFMA || ix->refs_bad) {
         if (prof) hipEventRecord(ix->ev[EV_BEGIN], st);
-        NNS_TRY(launch_exact_search(ix->k, m, ix->n, q_dev, ix->r_dev, ix->base, keys_dev, st));
+        if (bf16)
+            NNS_TRY(launch_exact_search_bf16(ix->k, m, ix->n, (const uint16_t *)q_dev, (const uint16_t *)ix->r_dev,
+                                             ix->base, keys_dev, st));
+        else
+            NNS_TRY(launch_exact_search(ix->k, m, ix->n, (const float *)q_dev, (const float *)ix->r_dev, ix->base,
+                                        keys_dev, st));
         if (prof) hipEventRecord(ix->ev[EV_END], st);
         ix->last_path = NNS_PATH_EXACT;
         ix->searched = true;
@@ -293,16 +328,24 @@ int nns_index_search(nns_index *ix, int m, const float *q_dev, nns_key *keys_dev
     // reset the per-search scalars (q max-abs, ambiguous count); keep the ref-side ones
     NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned), st));
     NNS_HIP(hipMemsetAsync(&ix->scal->amb_count, 0, sizeof(int), st));
-    NNS_TRY(launch_prep_image(ix->k, g.kt, m, g.m_pad, q_dev, ix->mean, 1.0f, 0.0f, ix->qimg,
-                              ix->qnorm, nullptr, &ix->scal->q_maxabs_bits, st));
+    if (bf16)
+        NNS_TRY(launch_prep_image_bf16(ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
+                                       nullptr, &ix->scal->q_maxabs_bits, st));
+    else
+        NNS_TRY(launch_prep_image(ix->k, g.kt, m, g.m_pad, (const float *)q_dev, ix->mean, 1.0f, 0.0f,
+                                  (float *)ix->qimg, ix->qnorm, nullptr, &ix->scal->q_maxabs_bits, st));
     if (prof) hipEventRecord(ix->ev[EV_QPREP], st);
     NNS_TRY(launch_filter(g, ix->qimg, ix->rimg, ix->rnorm, ix->qnorm, ix->scal, ix->lists, ix->counts, st));
     if (prof) hipEventRecord(ix->ev[EV_FILTER], st);
     NNS_TRY(launch_finalize(g, ix->k, m, ix->n, q_dev, ix->r_dev, ix->lists, ix->counts, ix->qnorm,
                             ix->scal, ix->base, keys_dev, ix->amb_list, st));
     if (prof) hipEventRecord(ix->ev[EV_FINAL], st);
-    NNS_TRY(launch_exact_listed(ix->k, ix->n, q_dev, ix->r_dev, ix->amb_list, &ix->scal->amb_count,
-                                m, ix->base, keys_dev, st));
+    if (bf16)
+        NNS_TRY(launch_exact_listed_bf16(ix->k, ix->n, (const uint16_t *)q_dev, (const uint16_t *)ix->r_dev,
+                                         ix->amb_list, &ix->scal->amb_count, m, ix->base, keys_dev, st));
+    else
+        NNS_TRY(launch_exact_listed(ix->k, ix->n, (const float *)q_dev, (const float *)ix->r_dev, ix->amb_list,
+                                    &ix->scal->amb_count, m, ix->base, keys_dev, st));
     if (prof) {
         hipEventRecord(ix->ev[EV_RERANK], st);
         hipEventRecord(ix->ev[EV_END], st);
@@ -310,6 +353,16 @@ int nns_index_search(nns_index *ix, int m, const float *q_dev, nns_key *keys_dev
     ix->last_path = NNS_PATH_MFMA;
     ix->searched = true;
     return NNS_OK;
+}
+
+int nns_index_search(nns_index *ix, int m, const float *q_dev, nns_key *keys_dev, void *stream)
+{
+    return index_search_impl(ix, m, q_dev, 0, keys_dev, stream);
+}
+
+int nns_index_search_bf16(nns_index *ix, int m, const uint16_t *q_dev, nns_key *keys_dev, void *stream)
+{
+    return index_search_impl(ix, m, q_dev, 1, keys_dev, stream);
 }
 
 int nns_index_stats(nns_index *ix, nns_stats *out)
@@ -387,9 +440,10 @@ int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const fl
     return rc;
 }
 
-int nns_search_f32_ex(int k, int m, int n, const float *s_points, const float *r_points,
-                      int *idx_out, float *dist_out, int num_shards, unsigned flags, int device)
+static int search_host_impl(int k, int m, int n, const void *s_points, const void *r_points, int bf16,
+                            int *idx_out, float *dist_out, int num_shards, unsigned flags, int device)
 {
+    const size_t esz = bf16 ? sizeof(uint16_t) : sizeof(float);
     if (k <= 0 || m <= 0 || n <= 0 || !s_points || !r_points || !idx_out) {
         set_error("nns_search_f32: k, m, n must be > 0 and pointers non-null (k=%d m=%d n=%d)", k, m, n);
         return NNS_ERR_INVALID;
@@ -402,14 +456,15 @@ int nns_search_f32_ex(int k, int m, int n, const float *s_points, const float *r
     if (num_shards < 1) num_shards = 1;
     if (num_shards > n) num_shards = n;   // the reference clamps GPUs to n (core.cu:771-772)
 
-    float *q_d = nullptr, *r_d = nullptr, *dist_d = nullptr;
+    char *q_d = nullptr, *r_d = nullptr;
+    float *dist_d = nullptr;
     nns_key *keys = nullptr, *keys_tmp = nullptr;
     int *idx_d = nullptr;
     hipStream_t st = nullptr;
     int rc = NNS_OK;
     nns_index *ix = nullptr;
     do {
-        const size_t qb = (size_t)m * k * sizeof(float), rb = (size_t)n * k * sizeof(float);
+        const size_t qb = (size_t)m * k * esz, rb = (size_t)n * k * esz;
         if (hipMalloc(&q_d, qb) != hipSuccess || hipMalloc(&r_d, rb) != hipSuccess ||
             hipMalloc(&keys, (size_t)m * sizeof(nns_key)) != hipSuccess ||
             hipMalloc(&keys_tmp, (size_t)m * sizeof(nns_key)) != hipSuccess ||
@@ -432,9 +487,9 @@ int nns_search_f32_ex(int k, int m, int n, const float *s_points, const float *r
             const int beg = s * per;
             const int cnt = (beg + per <= n) ? per : n - beg;
             if (cnt <= 0) break;
-            rc = nns_index_create(&ix, device, k, cnt, r_d + (size_t)beg * k, beg, flags, st);
+            rc = index_create_impl(&ix, device, k, cnt, r_d + (size_t)beg * k * esz, bf16, beg, flags, st);
             if (rc != NNS_OK) break;
-            rc = nns_index_search(ix, m, q_d, first ? keys : keys_tmp, st);
+            rc = index_search_impl(ix, m, q_d, bf16, first ? keys : keys_tmp, st);
             if (rc == NNS_OK && !first) rc = nns_keys_min(keys, keys_tmp, m, st);
             if (rc == NNS_OK && hipStreamSynchronize(st) != hipSuccess) {
                 set_error("nns_search_f32: kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
@@ -460,6 +515,18 @@ int nns_search_f32_ex(int k, int m, int n, const float *s_points, const float *r
     hipFree(idx_d);
     hipFree(dist_d);
     return rc;
+}
+
+int nns_search_f32_ex(int k, int m, int n, const float *s_points, const float *r_points, int *idx_out,
+                      float *dist_out, int num_shards, unsigned flags, int device)
+{
+    return search_host_impl(k, m, n, s_points, r_points, 0, idx_out, dist_out, num_shards, flags, device);
+}
+
+int nns_search_bf16_ex(int k, int m, int n, const uint16_t *s_points, const uint16_t *r_points, int *idx_out,
+                       float *dist_out, int num_shards, unsigned flags, int device)
+{
+    return search_host_impl(k, m, n, s_points, r_points, 1, idx_out, dist_out, num_shards, flags, device);
 }
 
 int nns_search_f32(int k, int m, int n, const float *s_points, const float *r_points, int **results)

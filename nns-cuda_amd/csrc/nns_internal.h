@@ -150,6 +150,12 @@ int launch_exact_listed(int k, int n, const float *q, const float *r,
                         const int *qlist, const int *qcount, int max_listed,
                         int64_t index_base, nns_key *keys, hipStream_t st);
 
+int launch_exact_search_bf16(int k, int m, int n, const uint16_t *q, const uint16_t *r,
+                             int64_t index_base, nns_key *keys, hipStream_t st);
+int launch_exact_listed_bf16(int k, int n, const uint16_t *q, const uint16_t *r, const int *qlist,
+                             const int *qcount, int max_listed, int64_t index_base, nns_key *keys,
+                             hipStream_t st);
+
 // prep_kernels.hip (K2)
 int prep_workspace_bytes(int kt, size_t *bytes);
 int launch_prep_mean(int k, int kt, int n, const float *r, double *partial_ws,
@@ -158,6 +164,12 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts,
                       const float *mean, float scale, float pad_norm,
                       float *img, float *norms, unsigned *max_norm_bits,
                       unsigned *maxabs_bits, hipStream_t st);
+
+// bf16 points (raw uint16 bits) -> bf16 tile image [blk][16][64 lanes][8 bf16], value * scale
+// (scale = 1 or -2, exact), fp32 norms of the UNcentred points, max-|v| word
+int launch_prep_image_bf16(int k, int npts, int npts_pad, const uint16_t *pts, float scale,
+                           float pad_norm, void *img, float *norms, unsigned *max_norm_bits,
+                           unsigned *maxabs_bits, hipStream_t st);
 
 // filter_mfma.hip (K3 fp32 / K4 bf16)
 int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g);

@@ -198,4 +198,85 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, c
     return NNS_OK;
 }
 
+// ---- bf16 image (K4's operands) --------------------------------------------------------
+// One workgroup = one block of 32 points, KT = 256.  The image is [16 steps][64 lanes][8 bf16]:
+// lane (i = lane & 31, h = lane >> 5) of step s holds dims 16s + 8h .. 16s + 8h + 7 of point
+// i — one v_mfma_f32_32x32x16_bf16 operand per ds_read_b128.  No centring (a centred bf16
+// value would need a second rounding); the scale (-2 for refs) is exact in bf16.
+__global__ __launch_bounds__(256) void image_bf16_kernel(int k, int npts, const uint16_t *__restrict__ pts,
+                                                         float scale, float pad_norm,
+                                                         uint16_t *__restrict__ img, float *__restrict__ norms,
+                                                         unsigned *__restrict__ max_norm_bits,
+                                                         unsigned *__restrict__ maxabs_bits)
+{
+    constexpr int KT = 256, LD = KT + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t tile[32 * LD];
+    __shared__ double nrm[32][8];
+    const int tid = threadIdx.x;
+    const int blk = blockIdx.x;
+    const int p0 = blk * 32;
+    unsigned mx = 0;
+    for (int e = tid; e < 32 * KT; e += 256) {
+        const int i = e / KT, t = e - i * KT;
+        uint16_t v = 0;
+        if (t < k && p0 + i < npts) {
+            v = pts[(size_t)(p0 + i) * k + t];
+            const unsigned b = ((unsigned)v << 16) & 0x7FFFFFFFu;
+            mx = b > mx ? b : mx;
+        }
+        tile[i * LD + t] = v;
+    }
+    __syncthreads();
+    {
+        const int i = tid >> 3, part = tid & 7;
+        double acc = 0.0;
+        for (int t = part; t < KT; t += 8) {
+            const double v = (double)__uint_as_float((unsigned)tile[i * LD + t] << 16);
+            acc += v * v;
+        }
+        nrm[i][part] = acc;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        double acc = 0.0;
+        for (int p = 0; p < 8; ++p) acc += nrm[tid][p];
+        float nv = (float)acc;
+        if (p0 + tid >= npts) nv = pad_norm;
+        else if (max_norm_bits) atomicMax(max_norm_bits, __float_as_uint(nv));
+        norms[p0 + tid] = nv;
+    }
+    // 16-byte fragments: f = s * 64 + lane
+    uint4 *out = reinterpret_cast<uint4 *>(img + (size_t)blk * 32 * KT);
+    for (int f = tid; f < 16 * 64; f += 256) {
+        const int s = f >> 6, lane = f & 63;
+        const int h = lane >> 5, i = lane & 31;
+        const uint16_t *src = &tile[i * LD + 16 * s + 8 * h];
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // scale in fp32 and narrow back: exact for scale in {1, -2} (no overflow below 1e17)
+            const float lo = __uint_as_float((unsigned)src[2 * e] << 16) * scale;
+            const float hi = __uint_as_float((unsigned)src[2 * e + 1] << 16) * scale;
+            w[e] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+        }
+        out[f] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    if ((tid & 63) == 0 && maxabs_bits) atomicMax(maxabs_bits, mx);
+}
+
+int launch_prep_image_bf16(int k, int npts, int npts_pad, const uint16_t *pts, float scale, float pad_norm,
+                           void *img, float *norms, unsigned *max_norm_bits, unsigned *maxabs_bits,
+                           hipStream_t st)
+{
+    hipLaunchKernelGGL(image_bf16_kernel, dim3(npts_pad / 32), dim3(256), 0, st, k, npts, pts, scale, pad_norm,
+                       (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
+    NNS_HIP(hipGetLastError());
+    return NNS_OK;
+}
+
 }  // namespace nns

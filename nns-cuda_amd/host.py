@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "nns_index_refresh", "nns_index_search", "nns_index_stats", "nns_keys_min",
     "nns_keys_unpack", "nns_fill_uniform", "nns_device_count", "nns_strerror",
     "nns_last_error", "nns_version", "nns_selftest_mfma",
+    "nns_index_create_bf16", "nns_index_search_bf16", "nns_search_bf16_ex",
 )
 
 
@@ -79,6 +80,9 @@ def _load() -> ctypes.CDLL:
     lib.nns_search_f32.argtypes = [c_int, c_int, c_int, c_vp, c_vp, ctypes.POINTER(ctypes.POINTER(c_int))]
     lib.nns_search_f32_ex.argtypes = [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_u, c_int]
     lib.nns_index_create.argtypes = [ctypes.POINTER(c_vp), c_int, c_int, c_int, c_vp, c_i64, c_u, c_vp]
+    lib.nns_index_create_bf16.argtypes = lib.nns_index_create.argtypes
+    lib.nns_index_search_bf16.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
+    lib.nns_search_bf16_ex.argtypes = lib.nns_search_f32_ex.argtypes
     lib.nns_index_destroy.argtypes = [c_vp]
     lib.nns_index_refresh.argtypes = [c_vp, c_vp]
     lib.nns_index_search.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
@@ -172,6 +176,35 @@ def search(query_points, reference_points, *, return_distances: bool = False, sh
     return (idx, dist) if return_distances else idx
 
 
+def to_bf16_bits(a) -> np.ndarray:
+    """fp32 array -> bf16 bit patterns (uint16), round-to-nearest-even (NaN stays NaN)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    u = a.view(np.uint32)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    nan = np.isnan(a)
+    if nan.any():
+        r[nan] = ((u[nan] >> 16) | 0x0040).astype(np.uint16)
+    return r
+
+
+def search_bf16(query_bits, reference_bits, *, return_distances: bool = False, shards: int = 1,
+                path: str = "auto", device: int = 0):
+    """search() for bf16 point sets given as uint16 bit patterns [points][k] (config C5):
+    V0's arithmetic on the bf16 values widened to fp32."""
+    q = np.ascontiguousarray(query_bits, dtype=np.uint16)
+    r = np.ascontiguousarray(reference_bits, dtype=np.uint16)
+    if q.ndim != 2 or r.ndim != 2 or q.shape[1] != r.shape[1]:
+        raise ValueError("bf16 point sets must be [points][k] with equal k")
+    m, k = q.shape
+    n = r.shape[0]
+    idx = np.empty(m, dtype=np.int32)
+    dist = np.empty(m, dtype=np.float32) if return_distances else None
+    _check(lib.nns_search_bf16_ex(k, m, n, q.ctypes.data, r.ctypes.data, idx.ctypes.data,
+                                  dist.ctypes.data if dist is not None else None, shards,
+                                  _PATHS[path], device), "nns_search_bf16_ex")
+    return (idx, dist) if return_distances else idx
+
+
 # ---------------------------------------------------------------------------
 # device-resident API (torch tensors are only the owners of device memory)
 # ---------------------------------------------------------------------------
@@ -193,15 +226,18 @@ class Index:
 
     def __init__(self, refs, *, index_base: int = 0, path: str = "auto", profile: bool = False, stream=None):
         import torch
-        if refs.dtype != torch.float32 or refs.dim() != 2 or not refs.is_contiguous() or not refs.is_cuda:
-            raise ValueError("refs must be a contiguous fp32 [n][k] tensor on a HIP device")
+        if refs.dtype not in (torch.float32, torch.bfloat16) or refs.dim() != 2 or not refs.is_contiguous() \
+                or not refs.is_cuda:
+            raise ValueError("refs must be a contiguous fp32 or bf16 [n][k] tensor on a HIP device")
+        self.bf16 = refs.dtype == torch.bfloat16
         self.refs = refs  # keep alive: the index reads the original values
         self.n, self.k = refs.shape
         self.device = refs.device.index or 0
         flags = _PATHS[path] | (NNS_PROFILE if profile else 0)
         h = ctypes.c_void_p()
-        _check(lib.nns_index_create(ctypes.byref(h), self.device, self.k, self.n, refs.data_ptr(),
-                                    index_base, flags, _stream_ptr(stream)), "nns_index_create")
+        create = lib.nns_index_create_bf16 if self.bf16 else lib.nns_index_create
+        _check(create(ctypes.byref(h), self.device, self.k, self.n, refs.data_ptr(),
+                      index_base, flags, _stream_ptr(stream)), "nns_index_create")
         self._h = h
 
     def refresh(self, stream=None) -> None:
@@ -210,15 +246,15 @@ class Index:
     def search_keys(self, queries, keys=None, stream=None):
         """Packed (V0 distance, global index) int64 key per query (NNS_KEY_NONE if none)."""
         import torch
-        if queries.dtype != torch.float32 or queries.dim() != 2 or not queries.is_contiguous():
-            raise ValueError("queries must be a contiguous fp32 [m][k] tensor")
+        if queries.dtype != self.refs.dtype or queries.dim() != 2 or not queries.is_contiguous():
+            raise ValueError("queries must be a contiguous [m][k] tensor of the index's dtype")
         if queries.shape[1] != self.k:
             raise ValueError("query dimensionality differs from the index")
         m = queries.shape[0]
         if keys is None:
             keys = torch.empty(m, dtype=torch.int64, device=queries.device)
-        _check(lib.nns_index_search(self._h, m, queries.data_ptr(), keys.data_ptr(), _stream_ptr(stream)),
-               "nns_index_search")
+        fn = lib.nns_index_search_bf16 if self.bf16 else lib.nns_index_search
+        _check(fn(self._h, m, queries.data_ptr(), keys.data_ptr(), _stream_ptr(stream)), "nns_index_search")
         return keys
 
     def search(self, queries, return_distances: bool = False, stream=None):

@@ -273,3 +273,63 @@ def test_headline_shape_properties(pkg, orc):
     torch.cuda.synchronize()
     k1.close()
     assert torch.equal(a, keys)
+
+
+# ---------------------------------------------------------------------------
+# bf16 points (config C5): oracle = V0 arithmetic on the bf16 values widened to fp32
+# ---------------------------------------------------------------------------
+def _check_bf16(pkg, orc, q, r, paths=("auto",), shards=(1,)):
+    qb, rb = pkg.to_bf16_bits(q), pkg.to_bf16_bits(r)
+    qw, rw = orc.round_bf16(q), orc.round_bf16(r)
+    assert np.array_equal((qw.view(np.uint32) >> 16).astype(np.uint16), qb)   # same rounding as the oracle
+    with np.errstate(all="ignore"):
+        want_idx, want_dist = orc.v0_search(qw, rw, threads=8)
+    for path in paths:
+        if path == "mfma" and q.shape[1] > 256:
+            continue
+        for s in shards:
+            idx, dist = pkg.search_bf16(qb, rb, return_distances=True, shards=s, path=path)
+            bad = np.nonzero(idx != want_idx)[0]
+            assert bad.size == 0, f"bf16 path={path} shards={s}: {bad.size} mismatches, first {bad[:5]}"
+            assert np.array_equal(_bits(dist), _bits(want_dist)), f"bf16 path={path} shards={s}: distance bits"
+
+
+@pytest.mark.parametrize("shape", [(300, 5000, 256), (700, 20001, 256), (33, 4097, 128), (1, 130, 256),
+                                   (513, 63, 200), (64, 3000, 40), (100, 2000, 16), (50, 999, 300)])
+def test_bf16_random_shapes(pkg, orc, shape):
+    m, n, k = shape
+    rng = np.random.default_rng(500 + m)
+    q = rng.random((m, k), dtype=np.float32)
+    r = rng.random((n, k), dtype=np.float32)
+    _check_bf16(pkg, orc, q, r, paths=("auto", "exact", "mfma"), shards=(1, 2))
+
+
+def test_bf16_ties_and_specials(pkg, orc):
+    rng = np.random.default_rng(8)
+    r = rng.random((400, 256), dtype=np.float32)
+    r = np.concatenate([r, r])                 # bf16 rounding also creates many exact ties
+    q = r[:100] + rng.normal(0, 1e-2, (100, 256)).astype(np.float32)
+    _check_bf16(pkg, orc, q, r, paths=("auto", "exact"), shards=(1, 3))
+    r2 = rng.random((300, 64), dtype=np.float32)
+    r2[5, 3] = np.nan
+    r2[9, 1] = np.inf
+    q2 = rng.random((20, 64), dtype=np.float32)
+    q2[2, 0] = np.nan
+    _check_bf16(pkg, orc, q2, r2, paths=("auto", "exact"), shards=(1, 2))
+
+
+def test_bf16_device_api(pkg, orc):
+    rng = np.random.default_rng(9)
+    q = rng.random((600, 256), dtype=np.float32)
+    r = rng.random((30000, 256), dtype=np.float32)
+    want_idx, want_dist = orc.v0_search(orc.round_bf16(q), orc.round_bf16(r), threads=8)
+    qd = torch.from_numpy(q).cuda().to(torch.bfloat16)
+    rd = torch.from_numpy(r).cuda().to(torch.bfloat16)
+    ix = pkg.Index(rd)
+    idx, dist = ix.search(qd, return_distances=True)
+    torch.cuda.synchronize()
+    st = ix.stats()
+    assert st["path"] == 2 and st["k_tile"] == 256, st
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+    assert np.array_equal(_bits(dist.cpu().numpy()), _bits(want_dist))
+    ix.close()
