@@ -33,7 +33,7 @@
 //     and stay resident.  A workgroup is 8 waves = 256 queries; all 8 waves consume the
 //     same stream of ref blocks from LDS (a block fetched once feeds 256 queries; the
 //     reference's V7 re-reads it per query).
-//   * refs stream through a 3-slot LDS ring (slot = 64 refs = 32 KiB of K2's tile image
+//   * refs stream through a 4-slot LDS ring (slot = 64 refs = 32 KiB of K2's tile image
 //     + 256 B of norms) filled by LDS-DMA (global_load_lds_dwordx4: the image is stored in
 //     LDS order, so the copy is linear, 1 KiB per wave-instruction), waited for with
 //     vmcnt and ONE raw s_barrier per slot; A fragments are lane-linear ds_read_b128
@@ -48,7 +48,10 @@
 //
 // Roofline: MFMA-bound.  fp32: 64 MFMAs x 64 cycles per 32x32x128 tile per SIMD; bf16:
 // 16 MFMAs x 32 cycles per 32x32x256 tile.  Algorithmic HBM traffic = the images once.
+#include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 #include "nns_internal.h"
 
 namespace nns {
@@ -67,9 +70,16 @@ __device__ __forceinline__ void static_for(F &&f)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Timing diagnostics only (results are wrong): build with -DNNS_FILTER_ABLATE=<bits>
+//   1 no ring sync (wait + barrier), 2 no epilogue, 16 no DMA issue.  0 in the product.
+#ifndef NNS_FILTER_ABLATE
+#define NNS_FILTER_ABLATE 0
+#endif
+constexpr int kAblate = NNS_FILTER_ABLATE;
+
 constexpr int F_NW = 8;                  // waves per workgroup (2 per SIMD)
 constexpr int F_SB = 2;                  // 32-ref image blocks per ring slot
-constexpr int F_D = 3;                   // ring depth
+constexpr int F_D = 4;                   // ring depth
 constexpr int F_QW = F_NW * 32;          // queries per workgroup
 constexpr int F_BLK_BYTES = 16384;       // one image block: 32 points x (128 fp32 | 256 bf16)
 constexpr int F_SLOT_COORD = F_SB * F_BLK_BYTES;
@@ -81,7 +91,10 @@ static_assert(F_SB * 32 == 64, "the norm piece is one dword per lane");
 
 // ---- operand traits ---------------------------------------------------------------
 struct OpF32 {   // KT = 128: float4 #b = operands of MFMA k-steps 4b .. 4b+3
-    static constexpr int kPrefetch = 2;   // fragments in flight ahead of the MFMAs (4 x 64 cycles each)
+#ifndef NNS_F_PF
+#define NNS_F_PF 2
+#endif
+    static constexpr int kPrefetch = NNS_F_PF;   // fragments in flight ahead of the MFMAs (4 x 64 cycles each)
     __device__ static __forceinline__ f32x16 mma(const float4 &a, const float4 &b, f32x16 acc)
     {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
@@ -135,7 +148,7 @@ struct FilterArgs {
     int *counts;            // [splits][m_pad/32][64 lanes]
     int total_slots, slots_per_split, m_pad, kt;
     int bf16;
-    int ablate;             // diagnostic (NNS_FILTER_ABLATE): 1 no ring sync/DMA, 2 no epilogue, 3 both
+    unsigned long long *stamps;   // diagnostic (NNS_FILTER_CLOCK): per-workgroup s_memtime / s_memrealtime
 };
 
 template <class OP>
@@ -163,19 +176,32 @@ __global__ __launch_bounds__(F_NW * 64) void filter_kernel(const FilterArgs a)
         asm volatile("" : "+v"(bq[b].x), "+v"(bq[b].y), "+v"(bq[b].z), "+v"(bq[b].w));
     asm volatile("" : "+v"(tc.c0), "+v"(tc.c1), "+v"(tc.x2));
 
+    unsigned long long st_t0 = 0, st_r0 = 0;
+    if (a.stamps) {   // diagnostic build of the launch only: in-kernel clock = d(memtime) / d(memrealtime) * 100 MHz
+        st_t0 = __builtin_amdgcn_s_memtime();
+        st_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     const int slot0 = blockIdx.y * a.slots_per_split;
     int ns = a.total_slots - slot0;
     if (ns > a.slots_per_split) ns = a.slots_per_split;
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
 
-    auto issue = [&](int s) {   // DMA of slot s (relative to slot0) into ring position s % F_D
+    // DMA piece p (0 .. F_PPW: 1 KiB image pieces, then the norm piece) of slot s (relative
+    // to slot0) into ring position s % F_D
+    auto issue_piece = [&](int s, int p) {
         const size_t gslot = (size_t)(slot0 + s);
-        const unsigned dst = lds_base + (s % F_D) * F_SLOT_BYTES;
-        const char *src = a.rimg + gslot * F_SLOT_COORD + wave * (F_PPW * 1024) + lane * 16;
+        const unsigned dst = lds_base + (s & (F_D - 1)) * F_SLOT_BYTES;
+        if (p < F_PPW) {
+            const int piece = wave * F_PPW + p;
+            dma16(a.rimg + gslot * F_SLOT_COORD + piece * 1024 + lane * 16, dst + piece * 1024);
+        } else {
+            // the slot's 64 norms: every wave copies the same 256 B (same bytes, same words)
+            dma4(a.rnorm + gslot * 64 + lane, dst + F_SLOT_COORD);
+        }
+    };
+    auto issue = [&](int s) {
 #pragma unroll
-        for (int i = 0; i < F_PPW; ++i) dma16(src + i * 1024, dst + wave * (F_PPW * 1024) + i * 1024);
-        // the slot's 64 norms: every wave copies the same 256 B (same bytes, same words)
-        dma4(a.rnorm + gslot * 64 + lane, dst + F_SLOT_COORD);
+        for (int p = 0; p <= F_PPW; ++p) issue_piece(s, p);
     };
 
     // ---- per-lane record state ---------------------------------------------------------
@@ -200,7 +226,7 @@ __global__ __launch_bounds__(F_NW * 64) void filter_kernel(const FilterArgs a)
     };
     // record collection over the 16 finished scores of one tile
     auto epilogue = [&](const f32x16 &acc, int blk_global) {
-        if (a.ablate & 2) {
+        if constexpr ((kAblate & 2) != 0) {
             asm volatile("" ::"v"(acc));
             return;
         }
@@ -240,84 +266,120 @@ __global__ __launch_bounds__(F_NW * 64) void filter_kernel(const FilterArgs a)
     // in accA, odd blocks in accB, so a finished tile's epilogue is issued one step INTO
     // the next tile's MFMA chain (its VALU work runs in the MFMA shadow) and the next
     // tile's norms are read straight into the free accumulator well ahead of its start.
-    // Fragments are prefetched PF steps ahead through a register ring.
+    // Fragments are prefetched PF steps ahead through a register ring that is carried
+    // ACROSS the barrier: the ring is 4 slots deep and the barrier of interval s confirms
+    // slot s + 1, so the first fragments (and the seed) of interval s + 1 are already in
+    // flight when its barrier releases and the MFMA chain restarts at once.
     constexpr int PF = OP::kPrefetch;
     constexpr int RING = 8;
-    static_assert(PF < RING, "prefetch ring too small");
+    static_assert(PF < RING && 32 % RING == 0, "prefetch ring");
     f32x16 accA, accB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accA[r] = accB[r] = __builtin_inff();
+    float4 fr[RING];
 
-    auto interval = [&](auto lag_c, const char *cur, const char *prev, int blk0_global, bool first) {
+    auto frag_ptr = [&](const char *slot, int blk, int f) {
+        return (reinterpret_cast<const float4 *>(slot + blk * F_BLK_BYTES) + lane) + f * 64;
+    };
+
+    // s: slot index relative to slot0; cur/prev/nxt: ring images of slots s, s-1, s+1
+    auto interval = [&](auto lag_c, int s, const char *cur, const char *prev, const char *nxt) {
         constexpr int LAG = decltype(lag_c)::value;
-        // compile-time schedule of step t
-        auto src_prev = [](int t) constexpr { return LAG == 1 && t < 8; };
+        const bool first = s == 0;
+        const int blk0_global = (slot0 + s) * F_SB;
+        // compile-time schedule of step t (t >= 32: step t - 32 of the NEXT interval)
         auto blk_of = [](int t) constexpr { return LAG == 0 ? t / 16 : (t < 8 ? 1 : (t < 24 ? 0 : 1)); };
         auto frag_of = [](int t) constexpr { return LAG == 0 ? t % 16 : (t < 8 ? 8 + t : (t < 24 ? t - 8 : t - 24)); };
-        constexpr int T0 = 0;
-        float4 fr[RING];
         auto load = [&](auto tc_) {
             constexpr int t = decltype(tc_)::value;
-            const char *base = src_prev(t) ? prev : cur;
-            fr[t % RING] = (reinterpret_cast<const float4 *>(base + blk_of(t) * F_BLK_BYTES) + lane)[frag_of(t) * 64];
+            if constexpr (t < 32) {
+                const char *base = (LAG == 1 && t < 8) ? prev : cur;
+                fr[t % RING] = *frag_ptr(base, blk_of(t), frag_of(t));
+            } else {   // next interval: LAG 0 reads the confirmed slot s+1, LAG 1 finishes this slot
+                constexpr int u = t - 32;   // (in the last interval LAG 0 reads a stale ring slot: unused)
+                fr[t % RING] = *frag_ptr(LAG == 1 ? cur : nxt, LAG == 1 ? 1 : 0, LAG == 1 ? 8 + u : u);
+            }
         };
-        // LAG = 1 in the very first interval has no previous slot: its steps 0..7 are skipped
-        static_for<PF>([&](auto t) {
-            if (!(LAG == 1 && decltype(t)::value < 8) || !first) load(t);
-        });
-        if (LAG == 0) seed(accA, cur, 0);                // block 0 starts this interval at once
         static_for<32>([&](auto tc_) {
             constexpr int t = decltype(tc_)::value;
             constexpr int blk = blk_of(t), b = frag_of(t);
-            if constexpr (t + PF < 32) {
-                if (!(LAG == 1 && t + PF < 8) || !first) load(std::integral_constant<int, t + PF>{});
+            load(std::integral_constant<int, t + PF>{});
+            // DMA two slots ahead, in the MFMA shadow (past the end: into the image's padding)
+            // one DMA piece per step, in the MFMA shadow, at different steps for the two SIMD
+            // partners (an LDS-DMA issue stalls the issuing wave for ~100 cycles)
+            if constexpr ((kAblate & 16) == 0) {
+                constexpr int d0 = LAG == 0 ? 2 : 18;
+                if constexpr (t >= d0 && t < d0 + 2 * (F_PPW + 1) && (t - d0) % 2 == 0) issue_piece(s + 2, (t - d0) / 2);
             }
-            if constexpr (LAG == 1 && t == T0) seed(accA, cur, 0);     // used from step 8 on
+            if constexpr (LAG == 1 && t == 0) seed(accA, cur, 0);          // used from step 8 on
             // the other accumulator is free once its epilogue (below) has run: seed it early
             if constexpr ((LAG == 0 && t == 4) || (LAG == 1 && t == 12)) seed(accB, cur, 1);
-            if (!(LAG == 1 && t < 8 && first)) {
-                if constexpr (blk == 0) accA = OP::mma(fr[t % RING], bq[b], accA);
-                else accB = OP::mma(fr[t % RING], bq[b], accB);
-            }
+            if constexpr (LAG == 0 && t == 28) seed(accA, nxt, 0);          // next interval's block 0
+            // (LAG 1, very first interval: steps 0..7 chew on a not-yet-written ring slot; their
+            //  accumulator is discarded below and re-seeded at step 12)
+            if constexpr (blk == 0) accA = OP::mma(fr[t % RING], bq[b], accA);
+            else accB = OP::mma(fr[t % RING], bq[b], accB);
             // deferred epilogues: one step into the following tile
             if constexpr ((LAG == 0 && t == 1) || (LAG == 1 && t == 9)) {
-                if (!first) epilogue(accB, blk0_global - 1);            // previous slot's block 1
+                if (!first) epilogue(accB, blk0_global - 1);                 // previous slot's block 1
             }
             if constexpr ((LAG == 0 && t == 17) || (LAG == 1 && t == 25)) epilogue(accA, blk0_global);
+#ifndef NNS_F_NOSCHED
             __builtin_amdgcn_sched_barrier(0);
+#endif
         });
     };
 
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     const bool lag = wave >= F_NW / 2;   // wave-uniform
+#ifdef NNS_F_PRIO
+    if (lag) __builtin_amdgcn_s_setprio(1);
+#endif
+    auto ring = [&](int s) { return smem + ((s + F_D) & (F_D - 1)) * F_SLOT_BYTES; };
+    static_assert((F_D & (F_D - 1)) == 0, "ring depth must be a power of two");
 
-    if (ns > 0) issue(0);
+    // prologue: slots 0 and 1 in flight; confirm slot 0; start interval 0's first fragments
+    issue(0);
+    issue(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(F_PPW + 1) : "memory");
+    __builtin_amdgcn_s_barrier();
+    // (LAG 1 reads ring slot -1 here: garbage in, discarded — see the interval)
+    static_for<PF>([&](auto t) {
+        constexpr int tt = decltype(t)::value;
+        fr[tt % RING] = *frag_ptr(lag ? ring(-1) : ring(0), lag ? 1 : 0, lag ? 8 + tt : tt);
+    });
+    if (!lag) seed(accA, ring(0), 0);
     for (int s = 0; s < ns; ++s) {
-        if (!(a.ablate & 1) || s == 0) {
-            // my share of slot s has landed (it is the only DMA in flight)
+        if constexpr ((kAblate & 1) == 0) {
+            // my share of slot s+1 has landed (issued an interval ago; the only DMA in flight)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // everyone's share has landed; everyone is done with slot s-2
+            // everyone's share of slot s+1 has landed; everyone is done with slot s-2
             __builtin_amdgcn_s_barrier();
-            if (s + 1 < ns) issue(s + 1);
         }
-        const char *cur = smem + (s % F_D) * F_SLOT_BYTES;
-        const char *prev = smem + ((s + F_D - 1) % F_D) * F_SLOT_BYTES;
-        const int blk0 = (slot0 + s) * F_SB;
-        if (!lag) interval(I0{}, cur, prev, blk0, s == 0);
-        else interval(I1{}, cur, prev, blk0, s == 0);
+        if (!lag) interval(I0{}, s, ring(s), ring(s - 1), ring(s + 1));
+        else interval(I1{}, s, ring(s), ring(s - 1), ring(s + 1));
     }
-    if (ns > 0) {
+    {
         const int last_blk1 = (slot0 + ns - 1) * F_SB + 1;
-        if (lag) {   // the lagging half block of the last slot
-            const char *last = smem + ((ns - 1) % F_D) * F_SLOT_BYTES;
-            const float4 *ap = reinterpret_cast<const float4 *>(last + F_BLK_BYTES) + lane;
-#pragma unroll
-            for (int b = F_STEPS / 2; b < F_STEPS; ++b) accB = OP::mma(ap[b * 64], bq[b], accB);
+        if (lag) {   // the lagging half block of the last slot; its first PF fragments are in the ring
+            const char *lastp = ring(ns - 1);
+            static_for<F_STEPS / 2>([&](auto tc_) {
+                constexpr int t = decltype(tc_)::value;
+                if constexpr (t + PF < F_STEPS / 2) fr[(t + PF) % RING] = *frag_ptr(lastp, 1, 8 + t + PF);
+                accB = OP::mma(fr[t % RING], bq[8 + t], accB);
+            });
         }
         epilogue(accB, last_blk1);
     }
     a.counts[lblk * 64 + lane] = cnt;
+    if (a.stamps && threadIdx.x == 0) {
+        unsigned long long *o = a.stamps + 4 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
+        o[0] = st_t0;
+        o[1] = st_r0;
+        o[2] = __builtin_amdgcn_s_memtime();
+        o[3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---- self-test: one 32x32 tile through the same MFMA k-order as the filter --------
@@ -425,10 +487,26 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
     a.m_pad = g.m_pad;
     a.kt = g.kt;
     a.bf16 = g.bf16;
-    const char *abl = getenv("NNS_FILTER_ABLATE");   // timing diagnostics only (results are wrong)
-    a.ablate = abl ? atoi(abl) : 0;
-    if (g.bf16) return launch_filter_t<OpBF16>(g, a, st);
-    return launch_filter_t<OpF32>(g, a, st);
+    a.stamps = nullptr;
+    const char *clk = getenv("NNS_FILTER_CLOCK");
+    const size_t nwg = (size_t)g.qgroups * g.splits;
+    if (clk && atoi(clk)) NNS_HIP(hipMalloc(&a.stamps, nwg * 4 * sizeof(unsigned long long)));
+    const int rc = g.bf16 ? launch_filter_t<OpBF16>(g, a, st) : launch_filter_t<OpF32>(g, a, st);
+    if (a.stamps) {   // diagnostic: synchronous read-out, median clock over workgroups
+        std::vector<unsigned long long> h(nwg * 4);
+        NNS_HIP(hipStreamSynchronize(st));
+        NNS_HIP(hipMemcpy(h.data(), a.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::vector<double> ghz;
+        for (size_t w = 0; w < nwg; ++w)
+            if (h[4 * w + 3] > h[4 * w + 1])
+                ghz.push_back((double)(h[4 * w + 2] - h[4 * w]) / (double)(h[4 * w + 3] - h[4 * w + 1]) * 0.1);
+        std::sort(ghz.begin(), ghz.end());
+        if (!ghz.empty())
+            fprintf(stderr, "[nns] filter in-kernel clock: median %.3f GHz (min %.3f, max %.3f) over %zu workgroups\n",
+                    ghz[ghz.size() / 2], ghz.front(), ghz.back(), ghz.size());
+        hipFree(a.stamps);
+    }
+    return rc;
 }
 
 }  // namespace nns

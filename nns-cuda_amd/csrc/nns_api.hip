@@ -198,8 +198,9 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
             const FilterGeom &g = ix->geom;
             size_t ws = 0;
             prep_workspace_bytes(g.kt, &ws);
-            if (hipMalloc(&ix->rimg, (size_t)g.n_pad * (F_IMG_ROW_BYTES)) != hipSuccess ||
-                hipMalloc(&ix->rnorm, (size_t)g.n_pad * sizeof(float)) != hipSuccess ||
+            // + 128 rows: the filter's ring DMA runs two 64-ref slots past the last one
+            if (hipMalloc(&ix->rimg, (size_t)(g.n_pad + 128) * (F_IMG_ROW_BYTES)) != hipSuccess ||
+                hipMalloc(&ix->rnorm, (size_t)(g.n_pad + 128) * sizeof(float)) != hipSuccess ||
                 hipMalloc(&ix->mean, (size_t)g.kt * sizeof(float)) != hipSuccess ||
                 hipMalloc(&ix->mean_ws, ws) != hipSuccess ||
                 hipMalloc(&ix->scal, sizeof(DevScalars)) != hipSuccess) {

@@ -23,7 +23,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnns_mi355x.so")
+LIB_PATH = os.environ.get("NNS_LIB_PATH") or os.path.join(_HERE, "libnns_mi355x.so")   # override: A/B of builds
 
 NNS_OK = 0
 NNS_PATH_AUTO, NNS_PATH_EXACT, NNS_PATH_MFMA, NNS_PROFILE = 0, 1, 2, 16

@@ -15,7 +15,7 @@ def main():
     ap.add_argument("--m", type=int, default=65536)
     ap.add_argument("--n", type=int, default=1048576)
     ap.add_argument("--k", type=int, default=128)
-    ap.add_argument("--variants", default="0", help="NNS_FILTER_ABLATE values to time (0 = the real kernel)")
+    ap.add_argument("--variants", default="0", help="labels only (ablations are compile-time: -DNNS_FILTER_ABLATE)")
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
     pkg = graft.load_package()
@@ -26,7 +26,6 @@ def main():
     flops = 2.0 * a.m * a.n * a.k
     ref_keys = None
     for v in [int(x) for x in a.variants.split(",")]:
-        os.environ["NNS_FILTER_ABLATE"] = str(v)
         ix = pkg.Index(r, path="mfma", profile=True)
         best = None
         for _ in range(a.reps):
@@ -39,7 +38,7 @@ def main():
         if ref_keys is None:
             ref_keys = keys.clone()
         tf = flops / (best["filter_ms"] * 1e-3) / 1e12
-        print(f"ablate {v}: filter {best['filter_ms']:.2f} ms = {tf:.1f} TF ({tf / 157.3 * 100:.1f}% of 157.3) "
+        print(f"run {v}: filter {best['filter_ms']:.2f} ms = {tf:.1f} TF ({tf / 157.3 * 100:.1f}% of 157.3) "
               f"| total {best['total_ms']:.2f} ms prepR {best['prep_refs_ms']:.2f} prepQ {best['prep_queries_ms']:.2f} "
               f"final {best['finalize_ms']:.2f} rerank {best['rerank_ms']:.2f} amb {best['ambiguous']} "
               f"splits {best['splits']} keys_equal_v0 {same}", flush=True)
