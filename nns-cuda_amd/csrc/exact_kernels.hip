@@ -120,7 +120,18 @@ __device__ __forceinline__ nns_key wave_min_key(nns_key v)
 // ---------------------------------------------------------------------------
 // K1a: lane = query, wave-uniform refs
 // ---------------------------------------------------------------------------
-constexpr int K1A_CHUNK = 8;   // refs whose distances are kept live for the chunk-min
+// K1a geometry: a workgroup stages its ref range in LDS once (coalesced), then every lane
+// walks it in chunks of CH refs read by BROADCAST ds_read_b128 (all lanes, same address:
+// one LDS access, no bank conflict) against QPL queries held in registers.  (Reading the
+// wave-uniform refs through the scalar cache instead thrashes it: 8 co-resident
+// workgroups stream 8 different ref ranges through 16 KiB.)
+constexpr int K1A_QPL = 2;          // queries per lane
+constexpr int K1A_LDS_FLOATS = 4096;   // 16 KiB ref tile
+
+template <int K>
+struct K1aChunk {
+    static constexpr int value = K <= 4 ? 8 : (K <= 8 ? 4 : 2);   // CH * K floats, multiple of 8
+};
 
 template <int K>
 __global__ __launch_bounds__(256) void exact_lane_query_kernel(
@@ -128,78 +139,148 @@ __global__ __launch_bounds__(256) void exact_lane_query_kernel(
     const float *__restrict__ r, int64_t index_base, nns_key *__restrict__ keys,
     int use_atomic)
 {
-    const int qi = blockIdx.x * 256 + threadIdx.x;
+    constexpr int CH = K1aChunk<K>::value;
+    constexpr int NF = CH * K;                       // floats per chunk (multiple of 8)
+    constexpr int TILE = K1A_LDS_FLOATS / K / CH * CH;   // refs per LDS tile (multiple of CH)
+    __shared__ __attribute__((aligned(16))) float sref[TILE * K];
     const int j0 = blockIdx.y * refs_per_split;
     int j1 = j0 + refs_per_split;
     if (j1 > n) j1 = n;
 
-    float qv[K];
+    int qi[K1A_QPL];
+    float qv[K1A_QPL][K];
+    float best[K1A_QPL];
+    int bidx[K1A_QPL];
 #pragma unroll
-    for (int t = 0; t < K; ++t) qv[t] = (qi < m) ? q[(size_t)qi * K + t] : 0.0f;
+    for (int u = 0; u < K1A_QPL; ++u) {
+        qi[u] = (blockIdx.x * K1A_QPL + u) * 256 + threadIdx.x;
+#pragma unroll
+        for (int t = 0; t < K; ++t) qv[u][t] = (qi[u] < m) ? q[(size_t)qi[u] * K + t] : 0.0f;
+        best[u] = __builtin_inff();
+        bidx[u] = 0;
+    }
 
-    float best = __builtin_inff();
-    int bidx = 0;
-    int j = j0;
-    // Chunked scan: per pair only the 3K distance ops + one v_min; the index of a
-    // new minimum is recovered in a (rare, wave-uniform) branch.  Ascending j and
-    // strict '<' keep V0's first-minimum rule inside the lane.
-    for (; j + K1A_CHUNK <= j1; j += K1A_CHUNK) {
-        float d[K1A_CHUNK];
+    for (int t0 = j0; t0 < j1; t0 += TILE) {
+        const int cnt = (j1 - t0) < TILE ? (j1 - t0) : TILE;
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * K; e += 256) sref[e] = r[(size_t)t0 * K + e];   // coalesced
+        __syncthreads();
+        int c = 0;
+        // Chunked scan: per pair only the 3K-1 distance ops + one v_min; the index of a new
+        // minimum is recovered in a (rare, wave-uniform) branch.  Ascending j and strict '<'
+        // keep V0's first-minimum rule inside the lane.
+        for (; c + CH <= cnt; c += CH) {
+            float cf[NF];
+            const float4 *src = reinterpret_cast<const float4 *>(sref + c * K);   // uniform address
 #pragma unroll
-        for (int c = 0; c < K1A_CHUNK; ++c) {
-            const float *rj = r + (size_t)(j + c) * K;   // wave-uniform -> s_load
-            float sum = 0.0f;
+            for (int e = 0; e < NF / 4; ++e) {
+                const float4 v = src[e];
+                cf[4 * e + 0] = v.x;
+                cf[4 * e + 1] = v.y;
+                cf[4 * e + 2] = v.z;
+                cf[4 * e + 3] = v.w;
+            }
 #pragma unroll
-            for (int t = 0; t < K; ++t) sum = v0_step(sum, qv[t], rj[t]);
-            d[c] = sum;
+            for (int u = 0; u < K1A_QPL; ++u) {
+                float d[CH];
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < K; ++t) sum = v0_step(sum, qv[u][t], cf[cc * K + t]);
+                    d[cc] = sum;
+                }
+                float cmin = d[0];
+#pragma unroll
+                for (int cc = 1; cc < CH; ++cc) cmin = fminf(cmin, d[cc]);   // NaN-ignoring min
+                const bool imp = cmin < best[u];                             // false for NaN / INF
+                if (__builtin_amdgcn_ballot_w64(imp) != 0ull) {
+                    if (imp) {
+                        best[u] = cmin;
+#pragma unroll
+                        for (int cc = CH - 1; cc >= 0; --cc)
+                            if (d[cc] == cmin) bidx[u] = t0 + c + cc;   // lowest index in the chunk wins
+                    }
+                }
+            }
         }
-        float cmin = d[0];
+        for (; c < cnt; ++c) {   // ragged tail of the tile
 #pragma unroll
-        for (int c = 1; c < K1A_CHUNK; ++c) cmin = fminf(cmin, d[c]);  // NaN-ignoring min
-        const bool imp = cmin < best;                                  // false for NaN / INF
-        if (__builtin_amdgcn_ballot_w64(imp) != 0ull) {
-            if (imp) {
-                best = cmin;
+            for (int u = 0; u < K1A_QPL; ++u) {
+                float sum = 0.0f;
 #pragma unroll
-                for (int c = K1A_CHUNK - 1; c >= 0; --c)
-                    if (d[c] == cmin) bidx = j + c;   // lowest index in the chunk wins
+                for (int t = 0; t < K; ++t) sum = v0_step(sum, qv[u][t], sref[c * K + t]);
+                if (best[u] > sum) {
+                    best[u] = sum;
+                    bidx[u] = t0 + c;
+                }
             }
         }
     }
-    for (; j < j1; ++j) {
-        const float *rj = r + (size_t)j * K;
-        float sum = 0.0f;
 #pragma unroll
-        for (int t = 0; t < K; ++t) sum = v0_step(sum, qv[t], rj[t]);
-        if (best > sum) {
-            best = sum;
-            bidx = j;
+    for (int u = 0; u < K1A_QPL; ++u)
+        if (qi[u] < m) {
+            const nns_key key = make_key(best[u], index_base + bidx[u]);
+            if (use_atomic == 1)
+                atomicMin((unsigned long long *)&keys[qi[u]], (unsigned long long)key);
+            else if (use_atomic == 2)
+                keys[(size_t)blockIdx.y * m + qi[u]] = key;   // per-split partial -> keys_colmin_kernel
+            else
+                keys[qi[u]] = key;
         }
-    }
-    if (qi < m) {
-        const nns_key key = make_key(best, index_base + bidx);
-        if (use_atomic)
-            atomicMin((unsigned long long *)&keys[qi], (unsigned long long)key);
-        else
-            keys[qi] = key;
+}
+
+// keys[i] = min over the splits of part[s][i]: the second stage of K1a (the reference's V7
+// does this step on the host, core.cu:675-696).  Plain coalesced traffic instead of
+// `splits` contended 64-bit atomics per query.  Workgroup = 32 queries x 8 split lanes.
+__global__ __launch_bounds__(256) void keys_colmin_kernel(const nns_key *__restrict__ part, int m, int splits,
+                                                          nns_key *__restrict__ keys)
+{
+    __shared__ nns_key red[8][32];
+    const int qi = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int g = threadIdx.x >> 5;
+    nns_key best = NNS_KEY_NONE;
+    if (qi < m)
+        for (int s = g; s < splits; s += 8) {
+            const nns_key v = part[(size_t)s * m + qi];
+            best = v < best ? v : best;
+        }
+    red[g][threadIdx.x & 31] = best;
+    __syncthreads();
+    if (g == 0 && qi < m) {
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {
+            const nns_key v = red[i][threadIdx.x];
+            best = v < best ? v : best;
+        }
+        keys[qi] = best;
     }
 }
 
 template <int K>
 static int launch_k1a(int m, int n, const float *q, const float *r, int64_t base,
-                      nns_key *keys, hipStream_t st)
+                      nns_key *keys, nns_key *ws, size_t ws_keys, hipStream_t st)
 {
-    const int qtiles = divup(m, 256);
-    const int qwaves = divup(m, 64);
+    const int qtiles = divup(m, 256 * K1A_QPL);
+    const int qwaves = divup(m, 64 * K1A_QPL);
     // enough waves to fill 256 CUs x 4 SIMDs a few times over, >= 256 refs per split
-    int splits = divup(16384, qwaves);
+    int splits = divup(8192, qwaves);
     const int max_splits = divup(n, 256);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
     int per = divup(n, splits);
-    per = divup(per, K1A_CHUNK) * K1A_CHUNK;
+    per = divup(per, K1aChunk<K>::value) * K1aChunk<K>::value;
     splits = divup(n, per);
+    if (splits > 1 && ws && ws_keys >= (size_t)splits * m) {
+        // two-stage: per-split partial keys, then a column min
+        hipLaunchKernelGGL(exact_lane_query_kernel<K>, dim3(qtiles, splits), dim3(256), 0, st,
+                           m, n, per, q, r, base, ws, 2);
+        NNS_HIP(hipGetLastError());
+        hipLaunchKernelGGL(keys_colmin_kernel, dim3(divup(m, 32)), dim3(256), 0, st, ws, m, splits, keys);
+        NNS_HIP(hipGetLastError());
+        return NNS_OK;
+    }
     if (splits > 1) NNS_TRY(launch_keys_fill(keys, m, NNS_KEY_NONE, st));
     hipLaunchKernelGGL(exact_lane_query_kernel<K>, dim3(qtiles, splits), dim3(256), 0, st,
                        m, n, per, q, r, base, keys, splits > 1 ? 1 : 0);
@@ -371,18 +452,29 @@ static int check_k(int k)
     return NNS_OK;
 }
 
+size_t exact_workspace_keys(int k, int m, int n)
+{
+    // upper bound of splits * m for K1a (see launch_k1a)
+    if (m < 64 || !(k == 1 || k == 2 || k == 3 || k == 4 || k == 8 || k == 16)) return 0;
+    int splits = divup(8192, divup(m, 64 * K1A_QPL));
+    const int max_splits = divup(n, 256);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 2) return 0;
+    return (size_t)(splits + 1) * m;
+}
+
 int launch_exact_search(int k, int m, int n, const float *q, const float *r,
-                        int64_t index_base, nns_key *keys, hipStream_t st)
+                        int64_t index_base, nns_key *keys, nns_key *ws, size_t ws_keys, hipStream_t st)
 {
     // K1a needs enough queries to fill lanes; its query lives in K registers
     if (m >= 64) {
         switch (k) {
-        case 1: return launch_k1a<1>(m, n, q, r, index_base, keys, st);
-        case 2: return launch_k1a<2>(m, n, q, r, index_base, keys, st);
-        case 3: return launch_k1a<3>(m, n, q, r, index_base, keys, st);
-        case 4: return launch_k1a<4>(m, n, q, r, index_base, keys, st);
-        case 8: return launch_k1a<8>(m, n, q, r, index_base, keys, st);
-        case 16: return launch_k1a<16>(m, n, q, r, index_base, keys, st);
+        case 1: return launch_k1a<1>(m, n, q, r, index_base, keys, ws, ws_keys, st);
+        case 2: return launch_k1a<2>(m, n, q, r, index_base, keys, ws, ws_keys, st);
+        case 3: return launch_k1a<3>(m, n, q, r, index_base, keys, ws, ws_keys, st);
+        case 4: return launch_k1a<4>(m, n, q, r, index_base, keys, ws, ws_keys, st);
+        case 8: return launch_k1a<8>(m, n, q, r, index_base, keys, ws, ws_keys, st);
+        case 16: return launch_k1a<16>(m, n, q, r, index_base, keys, ws, ws_keys, st);
         default: break;
         }
     }

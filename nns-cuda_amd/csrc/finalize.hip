@@ -41,6 +41,36 @@ __device__ __forceinline__ float load_f(const uint16_t *p, size_t i)
 {
     return __uint_as_float((unsigned)p[i] << 16);   // bf16 -> fp32 widening is exact
 }
+__device__ __forceinline__ float4 load_f4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 load_f4(const uint16_t *p)
+{
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    float4 o;
+    o.x = __uint_as_float(v.x << 16);
+    o.y = __uint_as_float(v.x & 0xFFFF0000u);
+    o.z = __uint_as_float(v.y << 16);
+    o.w = __uint_as_float(v.y & 0xFFFF0000u);
+    return o;
+}
+
+// V0's exact distance (core.cu:38-43), t ascending; 4 dims per load when aligned
+template <typename T>
+__device__ __forceinline__ float v0_distance(const T *qi, const T *rj, int k, bool vec)
+{
+    float sum = 0.0f;
+    if (vec) {
+        for (int t = 0; t < k; t += 4) {
+            const float4 qv = load_f4(qi + t), rv = load_f4(rj + t);
+            sum = v0_step(sum, qv.x, rv.x);
+            sum = v0_step(sum, qv.y, rv.y);
+            sum = v0_step(sum, qv.z, rv.z);
+            sum = v0_step(sum, qv.w, rv.w);
+        }
+    } else {
+        for (int t = 0; t < k; ++t) sum = v0_step(sum, load_f(qi, t), load_f(rj, t));
+    }
+    return sum;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void finalize_kernel(
@@ -73,6 +103,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(
         const TauConsts tc = tau_consts(kt, qnorm[i], __uint_as_float(scal->ymax2_bits), bf16 != 0);
         const float thr = a + tau_of(tc, a);
         const T *qi = q + (size_t)i * k;
+        const bool vec = (k & 3) == 0 && (((uintptr_t)q | (uintptr_t)r) & (4 * sizeof(T) - 1)) == 0;
         for (int s = 0; s < splits; ++s)
             for (int h = 0; h < 2; ++h) {
                 const size_t lblk = (size_t)s * (m_pad / 32) + (i >> 5);
@@ -82,10 +113,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(
                 for (int e = 0; e < c; ++e) {
                     const CandEntry ce = l[e * 64];
                     if (ce.s <= thr && ce.j < n) {
-                        // V0's exact distance (core.cu:38-43) of candidate ce.j
-                        const T *rj = r + (size_t)ce.j * k;
-                        float sum = 0.0f;
-                        for (int t = 0; t < k; ++t) sum = v0_step(sum, load_f(qi, t), load_f(rj, t));
+                        const float sum = v0_distance(qi, r + (size_t)ce.j * k, k, vec);
                         const nns_key key = make_key(sum, index_base + ce.j);
                         best = key < best ? key : best;
                     }

@@ -60,6 +60,10 @@ struct nns_index {
     size_t lists_cap = 0;         // in lane-lists
     int *amb_list = nullptr;
 
+    // exact path: per-split partial keys of K1a
+    nns_key *exact_ws = nullptr;
+    size_t exact_ws_keys = 0;
+
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
     bool searched = false;
@@ -139,6 +143,7 @@ int nns_index_destroy(nns_index *ix)
     hipFree(ix->lists);
     hipFree(ix->counts);
     hipFree(ix->amb_list);
+    hipFree(ix->exact_ws);
     if (ix->ev_valid)
         for (int i = 0; i < EV_COUNT; ++i) hipEventDestroy(ix->ev[i]);
     delete ix;
@@ -265,6 +270,7 @@ static int ensure_query_ws(nns_index *ix, int m)
         hipFree(ix->qimg);
         hipFree(ix->qnorm);
         hipFree(ix->amb_list);
+    hipFree(ix->exact_ws);
         ix->qimg = nullptr;
         ix->qnorm = nullptr;
         ix->amb_list = nullptr;
@@ -315,8 +321,18 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
             NNS_TRY(launch_exact_search_bf16(ix->k, m, ix->n, (const uint16_t *)q_dev, (const uint16_t *)ix->r_dev,
                                              ix->base, keys_dev, st));
         else
+        {
+            const size_t need = exact_workspace_keys(ix->k, m, ix->n);
+            if (need > ix->exact_ws_keys) {
+                hipFree(ix->exact_ws);
+                ix->exact_ws = nullptr;
+                ix->exact_ws_keys = 0;
+                if (hipMalloc(&ix->exact_ws, need * sizeof(nns_key)) == hipSuccess) ix->exact_ws_keys = need;
+                else (void)hipGetLastError();   // no workspace: K1a falls back to atomics
+            }
             NNS_TRY(launch_exact_search(ix->k, m, ix->n, (const float *)q_dev, (const float *)ix->r_dev, ix->base,
-                                        keys_dev, st));
+                                        keys_dev, ix->exact_ws, ix->exact_ws_keys, st));
+        }
         if (prof) hipEventRecord(ix->ev[EV_END], st);
         ix->last_path = NNS_PATH_EXACT;
         ix->searched = true;

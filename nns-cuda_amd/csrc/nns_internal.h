@@ -81,9 +81,9 @@ struct __attribute__((aligned(8))) CandEntry {
     int j;
 };
 // capacity of one lane's private candidate list (per split, query, lane half); a lane
-// collects ~ln(refs it sees) records, so 32 overflows only on adversarial inputs — an
+// collects ~ln(refs it sees) records, so 64 overflows only on adversarial inputs — an
 // overflowing query is re-ranked by the exact scan instead.
-constexpr int kCandCap = 32;
+constexpr int kCandCap = 64;
 
 // tau(a) = c0 + c1 * max(a + x2, 0): the margin within which a filter score cannot be
 // ordered against V0's fp32 distances (derivation: finalize.hip).  Shared by K3/K4 (which
@@ -142,8 +142,11 @@ int launch_keys_min(nns_key *inout, const nns_key *other, int m, hipStream_t st)
 int launch_keys_unpack(const nns_key *keys, int m, int *idx, float *dist, hipStream_t st);
 int launch_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset, hipStream_t st);
 // exact search of all m queries (K1a lane=query when k is small, else K1b)
+// ws: optional workspace of ws_keys keys (exact_workspace_keys) for the two-stage merge
+size_t exact_workspace_keys(int k, int m, int n);
 int launch_exact_search(int k, int m, int n, const float *q, const float *r,
-                        int64_t index_base, nns_key *keys, hipStream_t st);
+                        int64_t index_base, nns_key *keys, nns_key *ws, size_t ws_keys,
+                        hipStream_t st);
 // exact scan of the queries listed in qlist[0 .. *qcount) (device memory); keys
 // of listed queries must hold NNS_KEY_NONE on entry (atomic-min merge).
 int launch_exact_listed(int k, int n, const float *q, const float *r,

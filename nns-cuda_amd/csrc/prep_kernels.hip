@@ -26,38 +26,66 @@ namespace nns {
 
 constexpr int PREP_MEAN_BLOCKS = 1024;
 
+// max-reduction into one device word: a plain read first (the word only grows), so that
+// after the first few workgroups almost no atomic is issued — tens of thousands of
+// workgroups hammering one address otherwise serialise the whole pre-pass
+__device__ __forceinline__ void max_word(unsigned *word, unsigned v)
+{
+    if (v > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, v);
+}
+
 int prep_workspace_bytes(int kt, size_t *bytes)
 {
     *bytes = (size_t)PREP_MEAN_BLOCKS * kt * sizeof(double);
     return NNS_OK;
 }
 
-// stage 1: per-block column sums.  Thread (rl, col): col = tid % cw walks the
-// dims, rl = tid / cw walks the rows, so a wave reads consecutive floats.
+// stage 1: per-block column sums.  Thread (rl, c4): c4 walks the dims four at a time (one
+// 16-byte load per lane when k % 4 == 0), rl walks the rows, so a wave reads consecutive
+// bytes.  Sums are fp64 in a fixed order -> the mean is deterministic.
+template <int VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(int k, int kt, int n, int rows_per_block,
                                                      const float *__restrict__ r,
                                                      double *__restrict__ partial,
                                                      unsigned *__restrict__ maxabs_bits)
 {
     extern __shared__ double ssum[];   // [rl_count][kt]
-    const int cw = kt < 256 ? kt : 256;
+    const int cgroups = kt / VEC;                       // column groups per row
+    const int cw = cgroups < 256 ? cgroups : 256;
     const int rl_count = 256 / cw;
-    const int col0 = threadIdx.x % cw;
+    const int g0 = threadIdx.x % cw;
     const int rl = threadIdx.x / cw;
     const int row0 = blockIdx.x * rows_per_block;
     int row1 = row0 + rows_per_block;
     if (row1 > n) row1 = n;
     unsigned mx = 0;
-    for (int c = col0; c < kt; c += cw) {
-        double acc = 0.0;
+    for (int g = g0; g < cgroups; g += cw) {
+        double acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.0;
+        const int c = g * VEC;
         if (c < k && rl < rl_count)
             for (int j = row0 + rl; j < row1; j += rl_count) {
-                const float v = r[(size_t)j * k + c];
-                acc += (double)v;
-                const unsigned b = __float_as_uint(v) & 0x7FFFFFFFu;
-                mx = b > mx ? b : mx;
+                float v[VEC];
+                if (VEC == 4) {
+                    const float4 q = *reinterpret_cast<const float4 *>(r + (size_t)j * k + c);
+                    v[0] = q.x;
+                    v[VEC > 1 ? 1 : 0] = q.y;
+                    v[VEC > 2 ? 2 : 0] = q.z;
+                    v[VEC > 3 ? 3 : 0] = q.w;
+                } else {
+                    v[0] = r[(size_t)j * k + c];
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    acc[e] += (double)v[e];
+                    const unsigned b = __float_as_uint(v[e]) & 0x7FFFFFFFu;
+                    mx = b > mx ? b : mx;
+                }
             }
-        if (rl < rl_count) ssum[rl * kt + c] = acc;
+        if (rl < rl_count)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) ssum[rl * kt + c + e] = acc[e];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < kt; c += 256) {
@@ -71,18 +99,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(int k, int kt, int n, int r
         unsigned o = __shfl_xor(mx, off, 64);
         mx = o > mx ? o : mx;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(maxabs_bits, mx);
+    if ((threadIdx.x & 63) == 0) max_word(maxabs_bits, mx);
 }
 
-// stage 2: fixed-order sum of the partials -> fp32 mean
-__global__ void mean_kernel(int kt, int nblocks, int n, const double *__restrict__ partial,
-                            float *__restrict__ mean)
+// stage 2: one workgroup per dimension, fixed-shape tree over the partials -> fp32 mean
+__global__ __launch_bounds__(256) void mean_kernel(int kt, int nblocks, int n, const double *__restrict__ partial,
+                                                   float *__restrict__ mean)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= kt) return;
+    __shared__ double red[256];
+    const int c = blockIdx.x;
     double acc = 0.0;
-    for (int b = 0; b < nblocks; ++b) acc += partial[(size_t)b * kt + c];
-    mean[c] = (float)(acc / (double)n);
+    for (int b = threadIdx.x; b < nblocks; b += 256) acc += partial[(size_t)b * kt + c];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mean[c] = (float)(red[0] / (double)n);
 }
 
 int launch_prep_mean(int k, int kt, int n, const float *r, double *partial_ws, float *mean,
@@ -92,13 +126,18 @@ int launch_prep_mean(int k, int kt, int n, const float *r, double *partial_ws, f
     int rows = divup(n, nblocks);
     if (rows < 64) rows = 64;
     nblocks = divup(n, rows);
-    const int cw = kt < 256 ? kt : 256;
+    const bool vec = (k % 4 == 0) && (((uintptr_t)r & 15) == 0);
+    const int cgroups = vec ? kt / 4 : kt;
+    const int cw = cgroups < 256 ? cgroups : 256;
     const size_t lds = (size_t)(256 / cw) * kt * sizeof(double);
-    hipLaunchKernelGGL(colsum_kernel, dim3(nblocks), dim3(256), lds, st, k, kt, n, rows, r,
-                       partial_ws, maxabs_bits);
+    if (vec)
+        hipLaunchKernelGGL(colsum_kernel<4>, dim3(nblocks), dim3(256), lds, st, k, kt, n, rows, r, partial_ws,
+                           maxabs_bits);
+    else
+        hipLaunchKernelGGL(colsum_kernel<1>, dim3(nblocks), dim3(256), lds, st, k, kt, n, rows, r, partial_ws,
+                           maxabs_bits);
     NNS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(mean_kernel, dim3(divup(kt, 64)), dim3(64), 0, st, kt, nblocks, n,
-                       partial_ws, mean);
+    hipLaunchKernelGGL(mean_kernel, dim3(kt), dim3(256), 0, st, kt, nblocks, n, partial_ws, mean);
     NNS_HIP(hipGetLastError());
     return NNS_OK;
 }
@@ -121,16 +160,37 @@ __global__ __launch_bounds__(256) void image_kernel(int k, int npts, const float
 
     // load + centre: the 32 rows are one contiguous span of 32*k floats
     unsigned mx = 0;
-    for (int e = tid; e < 32 * KT; e += 256) {
-        const int i = e / KT, t = e - i * KT;
-        float c = 0.0f;
-        if (t < k && p0 + i < npts) {
-            const float v = pts[(size_t)(p0 + i) * k + t];
-            const unsigned b = __float_as_uint(v) & 0x7FFFFFFFu;
-            mx = b > mx ? b : mx;
-            c = __fsub_rn(v, mean[t]);   // ONE rounding: x' = fl(x - c)
+    if (k == KT && p0 + 32 <= npts && (((uintptr_t)pts) & 15) == 0) {
+        // full block of full-depth rows: 16-byte loads, consecutive lanes -> consecutive bytes
+        const float4 *src = reinterpret_cast<const float4 *>(pts + (size_t)p0 * KT);
+        const float4 *mean4 = reinterpret_cast<const float4 *>(mean);
+        for (int e = tid; e < 32 * (KT / 4); e += 256) {
+            const int i = e / (KT / 4), t4 = e - i * (KT / 4);
+            const float4 v = src[e];
+            const float4 mc = mean4[t4];
+            const unsigned b0 = __float_as_uint(v.x) & 0x7FFFFFFFu, b1 = __float_as_uint(v.y) & 0x7FFFFFFFu;
+            const unsigned b2 = __float_as_uint(v.z) & 0x7FFFFFFFu, b3 = __float_as_uint(v.w) & 0x7FFFFFFFu;
+            const unsigned bm = max(max(b0, b1), max(b2, b3));
+            mx = bm > mx ? bm : mx;
+            float4 c;   // ONE rounding each: x' = fl(x - c)
+            c.x = __fsub_rn(v.x, mc.x);
+            c.y = __fsub_rn(v.y, mc.y);
+            c.z = __fsub_rn(v.z, mc.z);
+            c.w = __fsub_rn(v.w, mc.w);
+            *reinterpret_cast<float4 *>(&tile[i * LD + 4 * t4]) = c;
         }
-        tile[i * LD + t] = c;
+    } else {
+        for (int e = tid; e < 32 * KT; e += 256) {
+            const int i = e / KT, t = e - i * KT;
+            float c = 0.0f;
+            if (t < k && p0 + i < npts) {
+                const float v = pts[(size_t)(p0 + i) * k + t];
+                const unsigned b = __float_as_uint(v) & 0x7FFFFFFFu;
+                mx = b > mx ? b : mx;
+                c = __fsub_rn(v, mean[t]);   // ONE rounding: x' = fl(x - c)
+            }
+            tile[i * LD + t] = c;
+        }
     }
     __syncthreads();
 
@@ -149,9 +209,18 @@ __global__ __launch_bounds__(256) void image_kernel(int k, int npts, const float
         double acc = 0.0;
         for (int p = 0; p < 8; ++p) acc += nrm[tid][p];
         float nv = (float)acc;
+        unsigned nb = 0;
         if (p0 + tid >= npts) nv = pad_norm;           // padding never wins (refs: +INF)
-        else if (max_norm_bits) atomicMax(max_norm_bits, __float_as_uint(nv));
+        else nb = __float_as_uint(nv);
         norms[p0 + tid] = nv;
+        if (max_norm_bits) {                           // block max (lanes 0..31), one update
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {
+                const unsigned o = __shfl_xor(nb, off, 64);
+                nb = o > nb ? o : nb;
+            }
+            if (tid == 0) max_word(max_norm_bits, nb);
+        }
     }
 
     // write the image: float4 #f of the block = img[b][lane][0..3], lane = 32h + i
@@ -173,7 +242,7 @@ __global__ __launch_bounds__(256) void image_kernel(int k, int npts, const float
         unsigned o = __shfl_xor(mx, off, 64);
         mx = o > mx ? o : mx;
     }
-    if ((tid & 63) == 0 && maxabs_bits) atomicMax(maxabs_bits, mx);
+    if ((tid & 63) == 0 && maxabs_bits) max_word(maxabs_bits, mx);
 }
 
 int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, const float *mean,
@@ -216,15 +285,30 @@ __global__ __launch_bounds__(256) void image_bf16_kernel(int k, int npts, const 
     const int blk = blockIdx.x;
     const int p0 = blk * 32;
     unsigned mx = 0;
-    for (int e = tid; e < 32 * KT; e += 256) {
-        const int i = e / KT, t = e - i * KT;
-        uint16_t v = 0;
-        if (t < k && p0 + i < npts) {
-            v = pts[(size_t)(p0 + i) * k + t];
-            const unsigned b = ((unsigned)v << 16) & 0x7FFFFFFFu;
-            mx = b > mx ? b : mx;
+    if (k == KT && p0 + 32 <= npts && (((uintptr_t)pts) & 15) == 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(pts + (size_t)p0 * KT);   // 8 bf16 per load
+        for (int e = tid; e < 32 * (KT / 8); e += 256) {
+            const int i = e / (KT / 8), t8 = e - i * (KT / 8);
+            const uint4 v = src[e];
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned lo = (w[u] << 16) & 0x7FFFFFFFu, hi = w[u] & 0x7FFF0000u;
+                mx = max(mx, max(lo, hi));
+            }
+            *reinterpret_cast<uint4 *>(&tile[i * LD + 8 * t8]) = v;
         }
-        tile[i * LD + t] = v;
+    } else {
+        for (int e = tid; e < 32 * KT; e += 256) {
+            const int i = e / KT, t = e - i * KT;
+            uint16_t v = 0;
+            if (t < k && p0 + i < npts) {
+                v = pts[(size_t)(p0 + i) * k + t];
+                const unsigned b = ((unsigned)v << 16) & 0x7FFFFFFFu;
+                mx = b > mx ? b : mx;
+            }
+            tile[i * LD + t] = v;
+        }
     }
     __syncthreads();
     {
@@ -241,22 +325,32 @@ __global__ __launch_bounds__(256) void image_bf16_kernel(int k, int npts, const 
         double acc = 0.0;
         for (int p = 0; p < 8; ++p) acc += nrm[tid][p];
         float nv = (float)acc;
+        unsigned nb = 0;
         if (p0 + tid >= npts) nv = pad_norm;
-        else if (max_norm_bits) atomicMax(max_norm_bits, __float_as_uint(nv));
+        else nb = __float_as_uint(nv);
         norms[p0 + tid] = nv;
+        if (max_norm_bits) {
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {
+                const unsigned o = __shfl_xor(nb, off, 64);
+                nb = o > nb ? o : nb;
+            }
+            if (tid == 0) max_word(max_norm_bits, nb);
+        }
     }
     // 16-byte fragments: f = s * 64 + lane
     uint4 *out = reinterpret_cast<uint4 *>(img + (size_t)blk * 32 * KT);
     for (int f = tid; f < 16 * 64; f += 256) {
         const int s = f >> 6, lane = f & 63;
         const int h = lane >> 5, i = lane & 31;
-        const uint16_t *src = &tile[i * LD + 16 * s + 8 * h];
+        const uint4 sv = *reinterpret_cast<const uint4 *>(&tile[i * LD + 16 * s + 8 * h]);
+        const unsigned in[4] = {sv.x, sv.y, sv.z, sv.w};
         unsigned w[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             // scale in fp32 and narrow back: exact for scale in {1, -2} (no overflow below 1e17)
-            const float lo = __uint_as_float((unsigned)src[2 * e] << 16) * scale;
-            const float hi = __uint_as_float((unsigned)src[2 * e + 1] << 16) * scale;
+            const float lo = __uint_as_float(in[e] << 16) * scale;
+            const float hi = __uint_as_float(in[e] & 0xFFFF0000u) * scale;
             w[e] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
         }
         out[f] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -266,7 +360,7 @@ __global__ __launch_bounds__(256) void image_bf16_kernel(int k, int npts, const 
         unsigned o = __shfl_xor(mx, off, 64);
         mx = o > mx ? o : mx;
     }
-    if ((tid & 63) == 0 && maxabs_bits) atomicMax(maxabs_bits, mx);
+    if ((tid & 63) == 0 && maxabs_bits) max_word(maxabs_bits, mx);
 }
 
 int launch_prep_image_bf16(int k, int npts, int npts_pad, const uint16_t *pts, float scale, float pad_norm,
