@@ -130,10 +130,95 @@ __global__ __launch_bounds__(256) void finalize_kernel(
     }
 }
 
+// Same result, one WAVE per query: with many ref-range splits (few queries) a query owns
+// 2 * splits candidate lists, and walking them from one thread serialises hundreds of
+// dependent loads.  Lanes take lists l, l + 64, ...; the minimum score and the final key
+// are reduced across the wave with packed-key / float shuffles.
+template <typename T>
+__global__ __launch_bounds__(256) void finalize_wave_kernel(
+    int kt, int bf16, int m_pad, int splits, int k, int m, int n, const T *__restrict__ q,
+    const T *__restrict__ r, const CandEntry *__restrict__ lists, const int *__restrict__ counts,
+    const float *__restrict__ qnorm, DevScalars *__restrict__ scal, int64_t index_base,
+    nns_key *__restrict__ keys, int *__restrict__ amb_list)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);   // wave-uniform query
+    if (i >= m) return;
+    const int nlists = 2 * splits;
+    bool fallback = scal->q_maxabs_bits >= kHugeBits || scal->r_maxabs_bits >= kHugeBits;
+    float a = __builtin_inff();
+    int over = 0;
+    for (int l = lane; l < nlists; l += 64) {
+        const int s = l >> 1, h = l & 1;
+        const size_t lblk = (size_t)s * (m_pad / 32) + (i >> 5);
+        const int ln = 32 * h + (i & 31);
+        const int c = counts[lblk * 64 + ln];
+        if (c > kCandCap) over = 1;
+        const CandEntry *lp = lists + lblk * (kCandCap * 64) + ln;
+        for (int e = 0; e < c && e < kCandCap; ++e) a = fminf(a, lp[e * 64].s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a = fminf(a, __shfl_xor(a, off, 64));
+        over |= __shfl_xor(over, off, 64);
+    }
+    if (over || !(a < __builtin_inff())) fallback = true;
+
+    nns_key best = NNS_KEY_NONE;
+    if (!fallback) {
+        const TauConsts tc = tau_consts(kt, qnorm[i], __uint_as_float(scal->ymax2_bits), bf16 != 0);
+        const float thr = a + tau_of(tc, a);
+        const T *qi = q + (size_t)i * k;
+        const bool vec = (k & 3) == 0 && (((uintptr_t)q | (uintptr_t)r) & (4 * sizeof(T) - 1)) == 0;
+        for (int l = lane; l < nlists; l += 64) {
+            const int s = l >> 1, h = l & 1;
+            const size_t lblk = (size_t)s * (m_pad / 32) + (i >> 5);
+            const int ln = 32 * h + (i & 31);
+            const int c = counts[lblk * 64 + ln];
+            const CandEntry *lp = lists + lblk * (kCandCap * 64) + ln;
+            for (int e = 0; e < c; ++e) {
+                const CandEntry ce = lp[e * 64];
+                if (ce.s <= thr && ce.j < n) {
+                    const float sum = v0_distance(qi, r + (size_t)ce.j * k, k, vec);
+                    const nns_key key = make_key(sum, index_base + ce.j);
+                    best = key < best ? key : best;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)best, off, 64);
+            const unsigned hi = __shfl_xor((unsigned)(best >> 32), off, 64);
+            const nns_key o = ((nns_key)hi << 32) | lo;
+            best = o < best ? o : best;
+        }
+        if (best == NNS_KEY_NONE) fallback = true;
+    }
+    if (lane == 0) {
+        keys[i] = fallback ? (nns_key)NNS_KEY_NONE : best;
+        if (fallback) {
+            const int pos = atomicAdd(&scal->amb_count, 1);
+            amb_list[pos] = i;
+        }
+    }
+}
+
 int launch_finalize(const FilterGeom &g, int k, int m, int n, const void *q, const void *r,
                     const CandEntry *lists, const int *counts, const float *qnorm, DevScalars *scal,
                     int64_t index_base, nns_key *keys, int *amb_list, hipStream_t st)
 {
+    if (g.splits >= 4) {   // few queries, many lists per query: one wave per query
+        if (g.bf16)
+            hipLaunchKernelGGL(finalize_wave_kernel<uint16_t>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, 1,
+                               g.m_pad, g.splits, k, m, n, (const uint16_t *)q, (const uint16_t *)r, lists,
+                               counts, qnorm, scal, index_base, keys, amb_list);
+        else
+            hipLaunchKernelGGL(finalize_wave_kernel<float>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, 0, g.m_pad,
+                               g.splits, k, m, n, (const float *)q, (const float *)r, lists, counts, qnorm, scal,
+                               index_base, keys, amb_list);
+        NNS_HIP(hipGetLastError());
+        return NNS_OK;
+    }
     if (g.bf16)
         hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(divup(m, 256)), dim3(256), 0, st, g.kt, 1, g.m_pad,
                            g.splits, k, m, n, (const uint16_t *)q, (const uint16_t *)r, lists, counts, qnorm,

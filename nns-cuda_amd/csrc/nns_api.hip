@@ -30,6 +30,9 @@ using namespace nns;
 
 // one point of either tile image is 512 bytes: 128 fp32 dims or 256 bf16 dims
 static const size_t F_IMG_ROW_BYTES = 512;
+// below this many queries the AUTO path skips the MFMA filter (and, in the whole-call
+// entry points, its ref pre-pass too)
+static const int kTinyM = 16;
 
 enum { EV_BEGIN = 0, EV_QPREP, EV_FILTER, EV_FINAL, EV_RERANK, EV_END, EV_R0, EV_R1, EV_COUNT };
 
@@ -315,7 +318,10 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
     const bool prof = ix->profile;
     ix->last_m = m;
 
-    if (ix->path != NNS_PATH_MFMA || ix->refs_bad) {
+    // A handful of queries cannot fill MFMA tiles (they are padded to 256): the ref stream
+    // is then HBM-bound and the exact lane-per-ref kernel is the faster path (AUTO only).
+    const bool tiny = (ix->flags & NNS_PATH_MASK) == NNS_PATH_AUTO && m < kTinyM;
+    if (ix->path != NNS_PATH_MFMA || ix->refs_bad || tiny) {
         if (prof) hipEventRecord(ix->ev[EV_BEGIN], st);
         if (bf16)
             NNS_TRY(launch_exact_search_bf16(ix->k, m, ix->n, (const uint16_t *)q_dev, (const uint16_t *)ix->r_dev,
@@ -472,6 +478,7 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
     NNS_TRY(ensure_device_ok(device));
     if (num_shards < 1) num_shards = 1;
     if (num_shards > n) num_shards = n;   // the reference clamps GPUs to n (core.cu:771-772)
+    if ((flags & NNS_PATH_MASK) == NNS_PATH_AUTO && m < kTinyM) flags |= NNS_PATH_EXACT;
 
     char *q_d = nullptr, *r_d = nullptr;
     float *dist_d = nullptr;

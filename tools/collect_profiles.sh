@@ -1,0 +1,34 @@
+#!/bin/bash
+# Collect the round's evidence on the GPU box: bench lines, rocprofv3 kernel stats, PMC passes.
+# usage (from the repo root, on the GPU box): bash tools/collect_profiles.sh <tag>
+TAG=${1:-r01}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for W in c3 c2 c5; do
+  timeout -k 10 300 python bench.py --workload $W --steps 10 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_$W.json
+  echo "bench $W: $(cut -c1-200 $OUT/bench_$W.json)"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- python3 bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats_$W.log 2>&1
+  cp $OUT/stats_$W/*/*kernel_stats.csv $OUT/kernel_stats_$W.csv 2>/dev/null
+done
+for W in c3 c5; do
+  for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
+    D=$OUT/pmc_${W}_$(echo $C | cut -d" " -f1)
+    timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline > $D.log 2>&1
+    echo "pmc $W $C exit $?"
+  done
+done
+timeout -k 10 300 ./nns-cuda_amd/nns_driver --repeat 3 > $OUT/driver.txt 2>&1
+timeout -k 10 300 python - > $OUT/wholecall_c3.txt 2>&1 <<'PY'
+import sys, time, numpy as np
+sys.path.insert(0, ".")
+import __graft_entry__ as g
+pkg = g.load_package(); orc = g.load_oracle()
+m, n, k = 65536, 1048576, 128
+q = orc.rng_uniform(m * k, 1000, 0).reshape(m, k); r = orc.rng_uniform(n * k, 1000, m * k).reshape(n, k)
+for rep in range(3):
+    t0 = time.perf_counter(); idx = pkg.cudaCall(k, m, n, q, r); dt = time.perf_counter() - t0
+    print(f"whole call nns_search_f32 (malloc + H2D of {(q.nbytes + r.nbytes) / 2**20:.0f} MiB pageable + search + D2H + free): {dt * 1e3:.1f} ms -> {m * n / dt:.3e} pairs/s")
+PY
+cat $OUT/wholecall_c3.txt | grep -v amdgpu
+ls $OUT
