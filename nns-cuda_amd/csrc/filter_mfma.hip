@@ -77,20 +77,35 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 constexpr int kAblate = NNS_FILTER_ABLATE;
 
-constexpr int F_NW = 8;                  // waves per workgroup (2 per SIMD)
 constexpr int F_SB = 2;                  // 32-ref image blocks per ring slot
 constexpr int F_D = 4;                   // ring depth
-constexpr int F_QW = F_NW * 32;          // queries per workgroup
 constexpr int F_BLK_BYTES = 16384;       // one image block: 32 points x (128 fp32 | 256 bf16)
 constexpr int F_SLOT_COORD = F_SB * F_BLK_BYTES;
 constexpr int F_SLOT_BYTES = F_SLOT_COORD + F_SB * 32 * 4;
-constexpr int F_PPW = F_SLOT_COORD / 1024 / F_NW;   // 1 KiB DMA pieces per wave per slot
 constexpr int F_LDS_BYTES = F_D * F_SLOT_BYTES;
 constexpr int F_STEPS = 16;              // ds_read_b128 per lane per image block
 static_assert(F_SB * 32 == 64, "the norm piece is one dword per lane");
 
 // ---- operand traits ---------------------------------------------------------------
+// query blocks (of 32) per wave: their B operands stay resident in VGPRs (64 each).  More
+// blocks = more MFMAs per LDS byte and per barrier interval, fewer waves' worth of registers.
+#ifndef NNS_F_QB_F32
+#define NNS_F_QB_F32 1
+#endif
+#ifndef NNS_F_QB_BF16
+#define NNS_F_QB_BF16 1
+#endif
+// waves per workgroup: 8 = two per SIMD (<= 256 VGPRs each), 4 = one per SIMD (<= 512)
+#ifndef NNS_F_NW_F32
+#define NNS_F_NW_F32 8
+#endif
+#ifndef NNS_F_NW_BF16
+#define NNS_F_NW_BF16 8
+#endif
+
 struct OpF32 {   // KT = 128: float4 #b = operands of MFMA k-steps 4b .. 4b+3
+    static constexpr int kQB = NNS_F_QB_F32;
+    static constexpr int kNW = NNS_F_NW_F32;
 #ifndef NNS_F_PF
 #define NNS_F_PF 2
 #endif
@@ -105,6 +120,8 @@ struct OpF32 {   // KT = 128: float4 #b = operands of MFMA k-steps 4b .. 4b+3
     }
 };
 struct OpBF16 {  // KT = 256: 16 bytes = 8 bf16 = one v_mfma_f32_32x32x16_bf16 operand
+    static constexpr int kQB = NNS_F_QB_BF16;
+    static constexpr int kNW = NNS_F_NW_BF16;
     static constexpr int kPrefetch = 6;   // one MFMA (32 cycles) per fragment: deeper prefetch
     __device__ static __forceinline__ f32x16 mma(const float4 &a, const float4 &b, f32x16 acc)
     {
@@ -152,29 +169,37 @@ struct FilterArgs {
 };
 
 template <class OP>
-__global__ __launch_bounds__(F_NW * 64) void filter_kernel(const FilterArgs a)
+__global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a)
 {
+    constexpr int F_NW = OP::kNW;
+    constexpr int F_PPW = F_SLOT_COORD / 1024 / F_NW;   // 1 KiB DMA pieces per wave per slot
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
-    const int qblk = blockIdx.x * F_NW + wave;
-    const int qi = qblk * 32 + (lane & 31);
+    constexpr int QB = OP::kQB;
+    const int qblk0 = (blockIdx.x * F_NW + wave) * QB;
 
-    // ---- resident B operands: this wave's 32 queries, all of K (64 VGPRs) ------------
-    float4 bq[F_STEPS];
-    {
-        const float4 *src = a.qimg + (size_t)qblk * (F_STEPS * 64) + lane;
+    // ---- resident B operands: this wave's QB x 32 queries, all of K (64 VGPRs each) ------
+    float4 bq[QB][F_STEPS];
+    TauConsts tc[QB];
 #pragma unroll
-        for (int b = 0; b < F_STEPS; ++b) bq[b] = src[b * 64];
+    for (int qb = 0; qb < QB; ++qb) {
+        const float4 *src = a.qimg + (size_t)(qblk0 + qb) * (F_STEPS * 64) + lane;
+#pragma unroll
+        for (int b = 0; b < F_STEPS; ++b) bq[qb][b] = src[b * 64];
+        tc[qb] = tau_consts(a.kt, a.qnorm[(qblk0 + qb) * 32 + (lane & 31)],
+                            __uint_as_float(a.scal->ymax2_bits), a.bf16 != 0);
     }
-    TauConsts tc = tau_consts(a.kt, a.qnorm[qi], __uint_as_float(a.scal->ymax2_bits), a.bf16 != 0);
     // Pin the loads here: hipcc must wait for them BEFORE the ring starts, not with a
     // vmcnt(0) at their first use inside the loop (it cannot see the asm DMAs).
 #pragma unroll
-    for (int b = 0; b < F_STEPS; ++b)
-        asm volatile("" : "+v"(bq[b].x), "+v"(bq[b].y), "+v"(bq[b].z), "+v"(bq[b].w));
-    asm volatile("" : "+v"(tc.c0), "+v"(tc.c1), "+v"(tc.x2));
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int b = 0; b < F_STEPS; ++b)
+            asm volatile("" : "+v"(bq[qb][b].x), "+v"(bq[qb][b].y), "+v"(bq[qb][b].z), "+v"(bq[qb][b].w));
+        asm volatile("" : "+v"(tc[qb].c0), "+v"(tc[qb].c1), "+v"(tc[qb].x2));
+    }
 
     unsigned long long st_t0 = 0, st_r0 = 0;
     if (a.stamps) {   // diagnostic build of the launch only: in-kernel clock = d(memtime) / d(memrealtime) * 100 MHz
@@ -205,27 +230,37 @@ __global__ __launch_bounds__(F_NW * 64) void filter_kernel(const FilterArgs a)
     };
 
     // ---- per-lane record state ---------------------------------------------------------
-    float m1 = __builtin_inff(), thr = __builtin_inff();
-    int cnt = 0;
+    float m1[QB], thr[QB];
+    int cnt[QB];
     // candidate lists are stored [split][query block][entry][lane] so that both the
     // appends of a wave and K5's per-query reads touch consecutive 8-byte words
-    const size_t lblk = (size_t)blockIdx.y * (a.m_pad / 32) + qblk;
-    CandEntry *const list = a.lists + lblk * (kCandCap * 64) + lane;
+    const size_t lblk0 = (size_t)blockIdx.y * (a.m_pad / 32) + qblk0;
+    CandEntry *list[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m1[qb] = thr[qb] = __builtin_inff();
+        cnt[qb] = 0;
+        list[qb] = a.lists + (lblk0 + qb) * (kCandCap * 64) + lane;
+    }
 
     // accumulators start at |y'_j|^2 of their rows: rows (r&3) + 8(r>>2) + 4h
-    auto seed = [&](f32x16 &acc, const char *slot, int blk) {
+    auto seed = [&](f32x16 (&acc)[QB], const char *slot, int blk) {
         const float *nrm = reinterpret_cast<const float *>(slot + F_SLOT_COORD) + blk * 32 + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 nv = *reinterpret_cast<const float4 *>(nrm + 8 * g);
-            acc[4 * g + 0] = nv.x;
-            acc[4 * g + 1] = nv.y;
-            acc[4 * g + 2] = nv.z;
-            acc[4 * g + 3] = nv.w;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                acc[qb][4 * g + 0] = nv.x;
+                acc[qb][4 * g + 1] = nv.y;
+                acc[qb][4 * g + 2] = nv.z;
+                acc[qb][4 * g + 3] = nv.w;
+            }
         }
     };
-    // record collection over the 16 finished scores of one tile
-    auto epilogue = [&](const f32x16 &acc, int blk_global) {
+    // record collection over the 16 finished scores of one tile of query block qb
+    auto epilogue1 = [&](const f32x16 &acc, int blk_global, auto qb_c) {
+        constexpr int qb = decltype(qb_c)::value;
         if constexpr ((kAblate & 2) != 0) {
             asm volatile("" ::"v"(acc));
             return;
@@ -236,26 +271,34 @@ __global__ __launch_bounds__(F_NW * 64) void filter_kernel(const FilterArgs a)
         const float t3 = fminf(fminf(acc[9], acc[10]), acc[11]);
         const float t4 = fminf(fminf(acc[12], acc[13]), acc[14]);
         const float tm = fminf(fminf(fminf(t0, t1), acc[15]), fminf(fminf(t2, t3), t4));
-        if (__builtin_amdgcn_ballot_w64(tm <= thr) != 0ull) {   // rare: ~ln(n) tiles per lane
+        if (__builtin_amdgcn_ballot_w64(tm <= thr[qb]) != 0ull) {   // rare: ~ln(n) tiles per lane
             const int jbase = blk_global * 32 + 4 * h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float x = acc[r];
-                if (x <= thr && x < __builtin_inff()) {
-                    if (cnt < kCandCap) {
+                if (x <= thr[qb] && x < __builtin_inff()) {
+                    if (cnt[qb] < kCandCap) {
                         CandEntry e;
                         e.s = x;
                         e.j = jbase + (r & 3) + 8 * (r >> 2);
-                        list[cnt * 64] = e;
+                        list[qb][cnt[qb] * 64] = e;
                     }
-                    ++cnt;   // > kCandCap marks overflow: K5 sends the query to the exact scan
-                    if (x < m1) {
-                        m1 = x;
-                        thr = x + tau_of(tc, x) * 1.002f;   // a hair wider than K5's own tau
+                    ++cnt[qb];   // > kCandCap marks overflow: K5 sends the query to the exact scan
+                    if (x < m1[qb]) {
+                        m1[qb] = x;
+                        thr[qb] = x + tau_of(tc[qb], x) * 1.002f;   // a hair wider than K5's own tau
                     }
                 }
             }
         }
+    };
+    auto epilogue = [&](const f32x16 (&acc)[QB], int blk_global) {
+        static_for<QB>([&](auto qb_c) { epilogue1(acc[decltype(qb_c)::value], blk_global, qb_c); });
+    };
+    auto mma_all = [&](f32x16 (&acc)[QB], const float4 &frag, auto b_c) {
+        constexpr int b = decltype(b_c)::value;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) acc[qb] = OP::mma(frag, bq[qb][b], acc[qb]);
     };
 
     // ---- the software pipeline of one barrier interval -----------------------------------
@@ -273,9 +316,11 @@ __global__ __launch_bounds__(F_NW * 64) void filter_kernel(const FilterArgs a)
     constexpr int PF = OP::kPrefetch;
     constexpr int RING = 8;
     static_assert(PF < RING && 32 % RING == 0, "prefetch ring");
-    f32x16 accA, accB;
+    f32x16 accA[QB], accB[QB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accA[r] = accB[r] = __builtin_inff();
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accA[qb][r] = accB[qb][r] = __builtin_inff();
     float4 fr[RING];
 
     auto frag_ptr = [&](const char *slot, int blk, int f) {
@@ -308,8 +353,11 @@ __global__ __launch_bounds__(F_NW * 64) void filter_kernel(const FilterArgs a)
             // one DMA piece per step, in the MFMA shadow, at different steps for the two SIMD
             // partners (an LDS-DMA issue stalls the issuing wave for ~100 cycles)
             if constexpr ((kAblate & 16) == 0) {
-                constexpr int d0 = LAG == 0 ? 2 : 18;
-                if constexpr (t >= d0 && t < d0 + 2 * (F_PPW + 1) && (t - d0) % 2 == 0) issue_piece(s + 2, (t - d0) / 2);
+                constexpr int d0 = LAG == 0 ? 2 : 16;
+                constexpr int sp = (F_PPW + 1) * 2 <= 14 ? 2 : 1;   // steps between pieces
+                static_assert(d0 + sp * (F_PPW + 1) <= 32, "DMA pieces must fit the interval");
+                if constexpr (t >= d0 && t < d0 + sp * (F_PPW + 1) && (t - d0) % sp == 0)
+                    issue_piece(s + 2, (t - d0) / sp);
             }
             if constexpr (LAG == 1 && t == 0) seed(accA, cur, 0);          // used from step 8 on
             // the other accumulator is free once its epilogue (below) has run: seed it early
@@ -317,8 +365,8 @@ __global__ __launch_bounds__(F_NW * 64) void filter_kernel(const FilterArgs a)
             if constexpr (LAG == 0 && t == 28) seed(accA, nxt, 0);          // next interval's block 0
             // (LAG 1, very first interval: steps 0..7 chew on a not-yet-written ring slot; their
             //  accumulator is discarded below and re-seeded at step 12)
-            if constexpr (blk == 0) accA = OP::mma(fr[t % RING], bq[b], accA);
-            else accB = OP::mma(fr[t % RING], bq[b], accB);
+            if constexpr (blk == 0) mma_all(accA, fr[t % RING], std::integral_constant<int, b>{});
+            else mma_all(accB, fr[t % RING], std::integral_constant<int, b>{});
             // deferred epilogues: one step into the following tile
             if constexpr ((LAG == 0 && t == 1) || (LAG == 1 && t == 9)) {
                 if (!first) epilogue(accB, blk0_global - 1);                 // previous slot's block 1
@@ -367,12 +415,13 @@ __global__ __launch_bounds__(F_NW * 64) void filter_kernel(const FilterArgs a)
             static_for<F_STEPS / 2>([&](auto tc_) {
                 constexpr int t = decltype(tc_)::value;
                 if constexpr (t + PF < F_STEPS / 2) fr[(t + PF) % RING] = *frag_ptr(lastp, 1, 8 + t + PF);
-                accB = OP::mma(fr[t % RING], bq[8 + t], accB);
+                mma_all(accB, fr[t % RING], std::integral_constant<int, 8 + t>{});
             });
         }
         epilogue(accB, last_blk1);
     }
-    a.counts[lblk * 64 + lane] = cnt;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) a.counts[(lblk0 + qb) * 64 + lane] = cnt[qb];
     if (a.stamps && threadIdx.x == 0) {
         unsigned long long *o = a.stamps + 4 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
         o[0] = st_t0;
@@ -438,11 +487,12 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g)
     }
     g->bf16 = bf16 ? 1 : 0;
     g->kt = kt;
-    g->m_pad = divup(m, F_QW) * F_QW;
+    const int qw = 32 * (bf16 ? OpBF16::kQB * OpBF16::kNW : OpF32::kQB * OpF32::kNW);   // queries per workgroup
+    g->m_pad = divup(m, qw) * qw;
     const int slot_pts = 32 * F_SB;
     g->n_pad = divup(n, slot_pts) * slot_pts;
     g->total_slots = g->n_pad / slot_pts;
-    g->qgroups = g->m_pad / F_QW;
+    g->qgroups = g->m_pad / qw;
     // one 8-wave workgroup is resident per CU (99 KiB of LDS): cover the 256 CUs
     int splits = 1;
     if (g->qgroups < 256) splits = divup(256, g->qgroups);
@@ -465,7 +515,7 @@ static int launch_filter_t(const FilterGeom &g, const FilterArgs &args, hipStrea
         NNS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(g.qgroups, g.splits), dim3(F_NW * 64), F_LDS_BYTES, st, args);
+    hipLaunchKernelGGL(kern, dim3(g.qgroups, g.splits), dim3(OP::kNW * 64), F_LDS_BYTES, st, args);
     NNS_HIP(hipGetLastError());
     return NNS_OK;
 }
