@@ -68,7 +68,8 @@ enum {
     NNS_PATH_EXACT = 1,  /* exact per-pair kernels only (V1..V9 arithmetic re-expressed) */
     NNS_PATH_MFMA = 2,   /* -2*Q*R^T MFMA filter + exact re-rank (k padded to the tile K) */
     NNS_PATH_MASK = 3,
-    NNS_PROFILE = 16     /* record HIP-event timings per stage (adds syncs at read-out) */
+    NNS_PROFILE = 16,    /* record HIP-event timings per stage (adds syncs at read-out) */
+    NNS_MULTI_VIRTUAL = 32 /* nns_search_f32_multi: allow more shards than GPUs (rehearsal) */
 };
 
 /*
@@ -117,6 +118,16 @@ int nns_search_f32(int k, int m, int n, const float *s_points,
 int nns_search_f32_ex(int k, int m, int n, const float *s_points,
                       const float *r_points, int *idx_out, float *dist_out,
                       int num_shards, unsigned flags, int device);
+
+/* The V8/V9 analogue (core.cu:761-853, 965-1057): refs sharded contiguously over
+ * num_devices GPUs (<= 0: all visible) by one host thread per GPU, per-GPU packed
+ * keys combined with ONE RCCL min all-reduce (uint64, ncclMin) over xGMI; falls back
+ * to one GPU for small problems exactly as the reference does (core.cu:775-777:
+ * n <= min(2^18, 1024 m)).  Result = V0's, for every m (the reference's own merge
+ * is wrong for m > 1). */
+int nns_search_f32_multi(int k, int m, int n, const float *s_points,
+                         const float *r_points, int *idx_out, float *dist_out,
+                         int num_devices, unsigned flags);
 
 /* ---- split API (device-resident buffers, caller's stream) ------------------ */
 

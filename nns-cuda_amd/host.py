@@ -26,7 +26,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NNS_LIB_PATH") or os.path.join(_HERE, "libnns_mi355x.so")   # override: A/B of builds
 
 NNS_OK = 0
-NNS_PATH_AUTO, NNS_PATH_EXACT, NNS_PATH_MFMA, NNS_PROFILE = 0, 1, 2, 16
+NNS_PATH_AUTO, NNS_PATH_EXACT, NNS_PATH_MFMA, NNS_PROFILE, NNS_MULTI_VIRTUAL = 0, 1, 2, 16, 32
 NNS_KEY_NONE = 0x7F80000000000000
 
 _PATHS = {"auto": NNS_PATH_AUTO, "exact": NNS_PATH_EXACT, "mfma": NNS_PATH_MFMA}
@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "nns_index_refresh", "nns_index_search", "nns_index_stats", "nns_keys_min",
     "nns_keys_unpack", "nns_fill_uniform", "nns_device_count", "nns_strerror",
     "nns_last_error", "nns_version", "nns_selftest_mfma",
-    "nns_index_create_bf16", "nns_index_search_bf16", "nns_search_bf16_ex",
+    "nns_index_create_bf16", "nns_index_search_bf16", "nns_search_bf16_ex", "nns_search_f32_multi",
 )
 
 
@@ -83,6 +83,7 @@ def _load() -> ctypes.CDLL:
     lib.nns_index_create_bf16.argtypes = lib.nns_index_create.argtypes
     lib.nns_index_search_bf16.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
     lib.nns_search_bf16_ex.argtypes = lib.nns_search_f32_ex.argtypes
+    lib.nns_search_f32_multi.argtypes = [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_u]
     lib.nns_index_destroy.argtypes = [c_vp]
     lib.nns_index_refresh.argtypes = [c_vp, c_vp]
     lib.nns_index_search.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
@@ -173,6 +174,26 @@ def search(query_points, reference_points, *, return_distances: bool = False, sh
     _check(lib.nns_search_f32_ex(k, m, n, q.ctypes.data, r.ctypes.data, idx.ctypes.data,
                                  dist.ctypes.data if dist is not None else None, shards,
                                  _PATHS[path], device), "nns_search_f32_ex")
+    return (idx, dist) if return_distances else idx
+
+
+def search_multi(query_points, reference_points, *, num_devices: int = 0, return_distances: bool = False,
+                 path: str = "auto", virtual: bool = False):
+    """The V8/V9 analogue: refs sharded over `num_devices` GPUs of this process (0 = all),
+    per-GPU keys combined with one RCCL min all-reduce.  `virtual` lets a 1-GPU box rehearse
+    more shards than it has GPUs (host-side key merge)."""
+    q = _as_f32(query_points, "query_points")
+    r = _as_f32(reference_points, "reference_points")
+    if q.shape[1] != r.shape[1]:
+        raise ValueError("query and reference dimensionality differ")
+    m, k = q.shape
+    n = r.shape[0]
+    idx = np.empty(m, dtype=np.int32)
+    dist = np.empty(m, dtype=np.float32) if return_distances else None
+    flags = _PATHS[path] | (NNS_MULTI_VIRTUAL if virtual else 0)
+    _check(lib.nns_search_f32_multi(k, m, n, q.ctypes.data, r.ctypes.data, idx.ctypes.data,
+                                    dist.ctypes.data if dist is not None else None, num_devices, flags),
+           "nns_search_f32_multi")
     return (idx, dist) if return_distances else idx
 
 

@@ -333,3 +333,19 @@ def test_bf16_device_api(pkg, orc):
     assert np.array_equal(idx.cpu().numpy(), want_idx)
     assert np.array_equal(_bits(dist.cpu().numpy()), _bits(want_dist))
     ix.close()
+
+
+def test_in_library_multi_gpu_path(pkg, orc):
+    """nns_search_f32_multi (the V8/V9 analogue): all visible GPUs, and a virtual rehearsal
+    with more shards than GPUs (one host thread per shard, host-side key merge)."""
+    rng = np.random.default_rng(55)
+    for (m, n, k) in [(300, 40000, 128), (1000, 300000, 3), (5, 7, 16)]:
+        q = rng.random((m, k), dtype=np.float32)
+        r = rng.random((n, k), dtype=np.float32)
+        r[n - 1] = r[0]
+        q[0] = r[0]                       # cross-shard exact tie -> lowest index
+        want_idx, want_dist = orc.v0_search(q, r, threads=8)
+        for kwargs in ({"num_devices": 0}, {"num_devices": 3, "virtual": True}, {"num_devices": 8, "virtual": True}):
+            idx, dist = pkg.search_multi(q, r, return_distances=True, **kwargs)
+            assert np.array_equal(idx, want_idx), kwargs
+            assert np.array_equal(_bits(dist), _bits(want_dist)), kwargs
