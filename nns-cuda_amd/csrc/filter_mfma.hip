@@ -122,7 +122,10 @@ struct OpF32 {   // KT = 128: float4 #b = operands of MFMA k-steps 4b .. 4b+3
 struct OpBF16 {  // KT = 256: 16 bytes = 8 bf16 = one v_mfma_f32_32x32x16_bf16 operand
     static constexpr int kQB = NNS_F_QB_BF16;
     static constexpr int kNW = NNS_F_NW_BF16;
-    static constexpr int kPrefetch = 6;   // one MFMA (32 cycles) per fragment: deeper prefetch
+#ifndef NNS_F_PF_BF16
+#define NNS_F_PF_BF16 6
+#endif
+    static constexpr int kPrefetch = NNS_F_PF_BF16;   // one MFMA (32 cycles) per fragment and query block: deeper prefetch
     __device__ static __forceinline__ f32x16 mma(const float4 &a, const float4 &b, f32x16 acc)
     {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // slot s + 1, so the first fragments (and the seed) of interval s + 1 are already in
     // flight when its barrier releases and the MFMA chain restarts at once.
     constexpr int PF = OP::kPrefetch;
-    constexpr int RING = 8;
+    constexpr int RING = PF < 4 ? 4 : 8;
     static_assert(PF < RING && 32 % RING == 0, "prefetch ring");
     f32x16 accA[QB], accB[QB];
 #pragma unroll

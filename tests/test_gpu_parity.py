@@ -349,3 +349,24 @@ def test_in_library_multi_gpu_path(pkg, orc):
             idx, dist = pkg.search_multi(q, r, return_distances=True, **kwargs)
             assert np.array_equal(idx, want_idx), kwargs
             assert np.array_equal(_bits(dist), _bits(want_dist)), kwargs
+
+
+def test_extreme_magnitudes(pkg, orc):
+    """Denormal-scale clouds (every squared distance underflows: all ties -> index 0 region)
+    and huge clouds (squares overflow: the error bound is void, exact kernels must take over)."""
+    rng = np.random.default_rng(91)
+    for scale, k in ((1e-25, 128), (1e-20, 64), (1e19, 128), (3e18, 16), (1e-38, 3)):
+        q = (rng.random((70, k), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+        r = (rng.random((3000, k), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+        with np.errstate(all="ignore"):
+            _check(pkg, orc, q, r, paths=("auto", "mfma") if k >= 32 else ("auto",), shards=(1, 2))
+
+
+def test_offset_clouds_need_centring(pkg, orc):
+    """Clouds far from the origin with tiny spread: un-centred GEMM scores would lose every
+    significant bit; the mean-centred filter plus the tau re-rank must still return V0's index."""
+    rng = np.random.default_rng(92)
+    for off, spread in ((1000.0, 1.0), (1.0e5, 10.0), (-3.0e4, 0.5)):
+        q = (off + spread * rng.random((130, 128))).astype(np.float32)
+        r = (off + spread * rng.random((6000, 128))).astype(np.float32)
+        _check(pkg, orc, q, r, paths=("mfma",), shards=(1, 3))
