@@ -391,6 +391,154 @@ __global__ __launch_bounds__(256) void exact_lane_ref_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// K1b, tiled: the same lane-per-ref scan with the refs staged through LDS so that every
+// global load instruction reads whole 128-byte lines (8 rows x 8 x 16 B) instead of one
+// 16-byte fragment from each of 64 rows.  Per wave and step: a sub-tile of 64 rows x 8
+// 16-byte chunks is loaded coalesced, written to a padded LDS image (row stride 144 B:
+// conflict-free ds_read_b128 with row = lane), read back one row per lane, and folded into
+// the QT running V0 chains (t ascending across steps).  The next sub-tile's global loads are
+// in flight while the current one is consumed.  Only the wave's own LDS region is touched
+// between the two workgroup barriers of a query group, so no barrier is needed per step.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void widen4(const float4 &raw, const float *, float (&o)[4])
+{
+    o[0] = raw.x; o[1] = raw.y; o[2] = raw.z; o[3] = raw.w;
+}
+__device__ __forceinline__ void widen8(const float4 &raw, float (&o)[8])   // 8 bf16 -> 8 fp32
+{
+    const unsigned w[4] = {__float_as_uint(raw.x), __float_as_uint(raw.y), __float_as_uint(raw.z), __float_as_uint(raw.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[2 * e] = __uint_as_float(w[e] << 16);
+        o[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u);
+    }
+}
+
+template <int QT, typename T>
+__global__ __launch_bounds__(256) void exact_lane_ref_tiled_kernel(
+    int k, int n, const T *__restrict__ q, const T *__restrict__ r,
+    const int *__restrict__ qlist, const int *__restrict__ qcount, int mq,
+    int64_t index_base, nns_key *__restrict__ keys)
+{
+    constexpr int EPC = 16 / sizeof(T);          // elements per 16-byte chunk (4 fp32 / 8 bf16)
+    constexpr int ROWB = 8 * 16 + 16;            // padded LDS row: 8 chunks + 16 B
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float *sq = smem_f;                                            // [QT][k] fp32 queries
+    char *stile = reinterpret_cast<char *>(smem_f + QT * k);       // [4 waves][64 rows][ROWB]
+    __shared__ nns_key wkeys[4][QT];
+    const int nq = qlist ? *qcount : mq;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char *mytile = stile + wave * (64 * ROWB);
+    const int kc = k / EPC;                       // 16-byte chunks per row
+    const char *rbytes = reinterpret_cast<const char *>(r);
+    const size_t row_bytes = (size_t)k * sizeof(T);
+
+    for (int g = blockIdx.y; g * QT < nq; g += gridDim.y) {
+        __syncthreads();
+        for (int e = tid; e < QT * k; e += 256) {
+            const int u = e / k, t = e - u * k;
+            const int qslot = g * QT + u;
+            float v = 0.0f;
+            if (qslot < nq) {
+                const int qi = qlist ? qlist[qslot] : qslot;
+                v = ld1(q + (size_t)qi * k + t);
+            }
+            sq[e] = v;
+        }
+        __syncthreads();
+
+        float best[QT];
+        int bidx[QT];
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+            best[u] = __builtin_inff();
+            bidx[u] = 0;
+        }
+        // this wave's rows: groups of 64, strided over all waves of the grid
+        const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+        for (int row0 = wave_global * 64; row0 < n; row0 += nwaves * 64) {
+            float sum[QT];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) sum[u] = 0.0f;
+            const int j = row0 + lane;
+            // load mapping: cpr chunks per row per step (8, or fewer for short rows); instruction i
+            // covers rows rpi*i .. rpi*i + rpi-1, lane -> (row rpi*i + lane/cpr, chunk lane%cpr), so a
+            // wave-instruction always reads 64 x 16 B in whole-row segments
+            const int cshift = kc >= 8 ? 3 : (kc >= 4 ? 2 : (kc >= 2 ? 1 : 0));
+            const int cpr = 1 << cshift, rpi = 64 >> cshift;
+            const int lrow = lane >> cshift, lch = lane & (cpr - 1);
+            float4 cur[8], nxt[8];
+            auto fetch = [&](float4 (&buf)[8], int c0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int rr = row0 + rpi * i + lrow;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i < cpr && rr < n && c0 + lch < kc)
+                        v = *reinterpret_cast<const float4 *>(rbytes + (size_t)rr * row_bytes + (size_t)(c0 + lch) * 16);
+                    buf[i] = v;
+                }
+            };
+            fetch(cur, 0);
+            for (int c0 = 0; c0 < kc; c0 += cpr) {
+                if (c0 + cpr < kc) fetch(nxt, c0 + cpr);
+                // stage: my fragments -> LDS image of this wave
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (i < cpr) *reinterpret_cast<float4 *>(mytile + (rpi * i + lrow) * ROWB + lch * 16) = cur[i];
+                __builtin_amdgcn_wave_barrier();
+                const int nc = (kc - c0) < cpr ? (kc - c0) : cpr;
+                for (int ch = 0; ch < nc; ++ch) {
+                    const float4 raw = *reinterpret_cast<const float4 *>(mytile + lane * ROWB + ch * 16);
+                    float rv[EPC];
+                    if constexpr (EPC == 4) widen4(raw, nullptr, reinterpret_cast<float (&)[4]>(rv));
+                    else widen8(raw, reinterpret_cast<float (&)[8]>(rv));
+                    const int t0 = (c0 + ch) * EPC;
+#pragma unroll
+                    for (int u = 0; u < QT; ++u) {
+                        float sacc = sum[u];
+#pragma unroll
+                        for (int e = 0; e < EPC; e += 4) {
+                            const float4 qv = *reinterpret_cast<const float4 *>(&sq[u * k + t0 + e]);   // broadcast
+                            sacc = v0_step(sacc, qv.x, rv[e + 0]);
+                            sacc = v0_step(sacc, qv.y, rv[e + 1]);
+                            sacc = v0_step(sacc, qv.z, rv[e + 2]);
+                            sacc = v0_step(sacc, qv.w, rv[e + 3]);
+                        }
+                        sum[u] = sacc;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();   // all rows read before the image is overwritten
+#pragma unroll
+                for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+            }
+            if (j < n) {
+#pragma unroll
+                for (int u = 0; u < QT; ++u)
+                    if (best[u] > sum[u]) {   // strict: first (lowest j) minimum of this lane
+                        best[u] = sum[u];
+                        bidx[u] = j;
+                    }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+            nns_key key = wave_min_key(make_key(best[u], index_base + bidx[u]));
+            if (lane == 0) wkeys[wave][u] = key;
+        }
+        __syncthreads();
+        if (tid < QT) {
+            nns_key key = wkeys[0][tid];
+            for (int w = 1; w < 4; ++w) key = wkeys[w][tid] < key ? wkeys[w][tid] : key;
+            const int qslot = g * QT + tid;
+            if (qslot < nq) {
+                const int qi = qlist ? qlist[qslot] : qslot;
+                atomicMin((unsigned long long *)&keys[qi], (unsigned long long)key);
+            }
+        }
+    }
+}
+
 template <int QT, typename T>
 static int launch_k1b_t(int k, int n, const T *q, const T *r, const int *qlist,
                         const int *qcount, int mq, int groups, int64_t base, nns_key *keys,
@@ -404,7 +552,14 @@ static int launch_k1b_t(int k, int n, const T *q, const T *r, const int *qlist,
     if (target < 1) target = 1;
     if (xblocks > target) xblocks = target;
     dim3 grid(xblocks, groups);
-    if (vec) {
+    const bool tiled = (k % (16 / (int)sizeof(T)) == 0) && (((uintptr_t)r & 15) == 0);
+    if (tiled) {
+        auto kern = exact_lane_ref_tiled_kernel<QT, T>;
+        const size_t lds_t = lds + 4 * 64 * (8 * 16 + 16);
+        if (lds_t > 48 * 1024)
+            NNS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds_t, st, k, n, q, r, qlist, qcount, mq, base, keys);
+    } else if (vec) {
         auto kern = exact_lane_ref_kernel<QT, 4, T>;
         if (lds > 48 * 1024)
             NNS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

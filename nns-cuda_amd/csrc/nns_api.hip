@@ -32,7 +32,7 @@ using namespace nns;
 static const size_t F_IMG_ROW_BYTES = 512;
 // below this many queries the AUTO path skips the MFMA filter (and, in the whole-call
 // entry points, its ref pre-pass too)
-static const int kTinyM = 16;
+static const int kTinyM = 64;
 
 enum { EV_BEGIN = 0, EV_QPREP, EV_FILTER, EV_FINAL, EV_RERANK, EV_END, EV_R0, EV_R1, EV_COUNT };
 
