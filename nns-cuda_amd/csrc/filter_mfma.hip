@@ -70,6 +70,24 @@ __device__ __forceinline__ void static_for(F &&f)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// accumulators of a wave's query blocks as NAMED members (an array of ext-vectors passed by
+// reference is not scalarised by hipcc and lands in scratch)
+struct AccSet {
+    f32x16 v0, v1;
+    template <int I>
+    __device__ __forceinline__ f32x16 &at()
+    {
+        if constexpr (I == 0) return v0;
+        else return v1;
+    }
+    template <int I>
+    __device__ __forceinline__ const f32x16 &at() const
+    {
+        if constexpr (I == 0) return v0;
+        else return v1;
+    }
+};
+
 // Timing diagnostics only (results are wrong): build with -DNNS_FILTER_ABLATE=<bits>
 //   1 no ring sync (wait + barrier), 2 no epilogue, 16 no DMA issue.  0 in the product.
 #ifndef NNS_FILTER_ABLATE
@@ -90,10 +108,10 @@ static_assert(F_SB * 32 == 64, "the norm piece is one dword per lane");
 // query blocks (of 32) per wave: their B operands stay resident in VGPRs (64 each).  More
 // blocks = more MFMAs per LDS byte and per barrier interval, fewer waves' worth of registers.
 #ifndef NNS_F_QB_F32
-#define NNS_F_QB_F32 1
+#define NNS_F_QB_F32 2
 #endif
 #ifndef NNS_F_QB_BF16
-#define NNS_F_QB_BF16 1
+#define NNS_F_QB_BF16 2
 #endif
 // waves per workgroup: 8 = two per SIMD (<= 256 VGPRs each), 4 = one per SIMD (<= 512)
 #ifndef NNS_F_NW_F32
@@ -123,7 +141,7 @@ struct OpBF16 {  // KT = 256: 16 bytes = 8 bf16 = one v_mfma_f32_32x32x16_bf16 o
     static constexpr int kQB = NNS_F_QB_BF16;
     static constexpr int kNW = NNS_F_NW_BF16;
 #ifndef NNS_F_PF_BF16
-#define NNS_F_PF_BF16 6
+#define NNS_F_PF_BF16 2
 #endif
     static constexpr int kPrefetch = NNS_F_PF_BF16;   // one MFMA (32 cycles) per fragment and query block: deeper prefetch
     __device__ static __forceinline__ f32x16 mma(const float4 &a, const float4 &b, f32x16 acc)
@@ -141,6 +159,7 @@ struct OpBF16 {  // KT = 256: 16 bytes = 8 bf16 = one v_mfma_f32_32x32x16_bf16 o
 // barrier.  M0 is compiler-reserved: saved and restored inside the same statement.
 __device__ __forceinline__ void dma16(const void *g, unsigned lds_byte)
 {
+    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);   // wave-uniform by construction: keep it scalar
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -150,6 +169,7 @@ __device__ __forceinline__ void dma16(const void *g, unsigned lds_byte)
 }
 __device__ __forceinline__ void dma4(const void *g, unsigned lds_byte)
 {
+    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                  "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
@@ -216,7 +236,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
 
     // DMA piece p (0 .. F_PPW: 1 KiB image pieces, then the norm piece) of slot s (relative
     // to slot0) into ring position s % F_D
-    auto issue_piece = [&](int s, int p) {
+    auto issue_piece = [&](int s, int p) __attribute__((always_inline)) {
         const size_t gslot = (size_t)(slot0 + s);
         const unsigned dst = lds_base + (s & (F_D - 1)) * F_SLOT_BYTES;
         if (p < F_PPW) {
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             dma4(a.rnorm + gslot * 64 + lane, dst + F_SLOT_COORD);
         }
     };
-    auto issue = [&](int s) {
+    auto issue = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p <= F_PPW; ++p) issue_piece(s, p);
     };
@@ -247,22 +267,24 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     }
 
     // accumulators start at |y'_j|^2 of their rows: rows (r&3) + 8(r>>2) + 4h
-    auto seed = [&](f32x16 (&acc)[QB], const char *slot, int blk) {
+    static_assert(QB <= 2, "AccSet holds two query blocks");
+    auto seed = [&](AccSet &acc, const char *slot, int blk) __attribute__((always_inline)) {
         const float *nrm = reinterpret_cast<const float *>(slot + F_SLOT_COORD) + blk * 32 + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 nv = *reinterpret_cast<const float4 *>(nrm + 8 * g);
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                acc[qb][4 * g + 0] = nv.x;
-                acc[qb][4 * g + 1] = nv.y;
-                acc[qb][4 * g + 2] = nv.z;
-                acc[qb][4 * g + 3] = nv.w;
-            }
+            // (compile-time qb: a runtime-looking index would send the accumulators to scratch)
+            static_for<QB>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int qb = decltype(qc)::value;
+                acc.template at<qb>()[4 * g + 0] = nv.x;
+                acc.template at<qb>()[4 * g + 1] = nv.y;
+                acc.template at<qb>()[4 * g + 2] = nv.z;
+                acc.template at<qb>()[4 * g + 3] = nv.w;
+            });
         }
     };
     // record collection over the 16 finished scores of one tile of query block qb
-    auto epilogue1 = [&](const f32x16 &acc, int blk_global, auto qb_c) {
+    auto epilogue1 = [&](const f32x16 &acc, int blk_global, auto qb_c) __attribute__((always_inline)) {
         constexpr int qb = decltype(qb_c)::value;
         if constexpr ((kAblate & 2) != 0) {
             asm volatile("" ::"v"(acc));
@@ -295,13 +317,15 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             }
         }
     };
-    auto epilogue = [&](const f32x16 (&acc)[QB], int blk_global) {
-        static_for<QB>([&](auto qb_c) { epilogue1(acc[decltype(qb_c)::value], blk_global, qb_c); });
+    auto epilogue = [&](const AccSet &acc, int blk_global) __attribute__((always_inline)) {
+        static_for<QB>([&](auto qb_c) __attribute__((always_inline)) { epilogue1(acc.template at<decltype(qb_c)::value>(), blk_global, qb_c); });
     };
-    auto mma_all = [&](f32x16 (&acc)[QB], const float4 &frag, auto b_c) {
+    auto mma_all = [&](AccSet &acc, const float4 &frag, auto b_c) __attribute__((always_inline)) {
         constexpr int b = decltype(b_c)::value;
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) acc[qb] = OP::mma(frag, bq[qb][b], acc[qb]);
+        static_for<QB>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int qb = decltype(qc)::value;
+            acc.template at<qb>() = OP::mma(frag, bq[qb][b], acc.template at<qb>());
+        });
     };
 
     // ---- the software pipeline of one barrier interval -----------------------------------
@@ -317,28 +341,27 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // slot s + 1, so the first fragments (and the seed) of interval s + 1 are already in
     // flight when its barrier releases and the MFMA chain restarts at once.
     constexpr int PF = OP::kPrefetch;
+    constexpr bool DB = QB == 1;   // two accumulator sets (deferred epilogue) only when they fit
     constexpr int RING = PF < 4 ? 4 : 8;
     static_assert(PF < RING && 32 % RING == 0, "prefetch ring");
-    f32x16 accA[QB], accB[QB];
+    AccSet accA, accB;
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accA[qb][r] = accB[qb][r] = __builtin_inff();
+    for (int r = 0; r < 16; ++r) accA.v0[r] = accA.v1[r] = accB.v0[r] = accB.v1[r] = __builtin_inff();
     float4 fr[RING];
 
-    auto frag_ptr = [&](const char *slot, int blk, int f) {
+    auto frag_ptr = [&](const char *slot, int blk, int f) __attribute__((always_inline)) {
         return (reinterpret_cast<const float4 *>(slot + blk * F_BLK_BYTES) + lane) + f * 64;
     };
 
     // s: slot index relative to slot0; cur/prev/nxt: ring images of slots s, s-1, s+1
-    auto interval = [&](auto lag_c, int s, const char *cur, const char *prev, const char *nxt) {
+    auto interval = [&](auto lag_c, int s, const char *cur, const char *prev, const char *nxt) __attribute__((always_inline)) {
         constexpr int LAG = decltype(lag_c)::value;
         const bool first = s == 0;
         const int blk0_global = (slot0 + s) * F_SB;
         // compile-time schedule of step t (t >= 32: step t - 32 of the NEXT interval)
         auto blk_of = [](int t) constexpr { return LAG == 0 ? t / 16 : (t < 8 ? 1 : (t < 24 ? 0 : 1)); };
         auto frag_of = [](int t) constexpr { return LAG == 0 ? t % 16 : (t < 8 ? 8 + t : (t < 24 ? t - 8 : t - 24)); };
-        auto load = [&](auto tc_) {
+        auto load = [&](auto tc_) __attribute__((always_inline)) {
             constexpr int t = decltype(tc_)::value;
             if constexpr (t < 32) {
                 const char *base = (LAG == 1 && t < 8) ? prev : cur;
@@ -348,7 +371,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                 fr[t % RING] = *frag_ptr(LAG == 1 ? cur : nxt, LAG == 1 ? 1 : 0, LAG == 1 ? 8 + u : u);
             }
         };
-        static_for<32>([&](auto tc_) {
+        static_for<32>([&](auto tc_) __attribute__((always_inline)) {
             constexpr int t = decltype(tc_)::value;
             constexpr int blk = blk_of(t), b = frag_of(t);
             load(std::integral_constant<int, t + PF>{});
@@ -362,19 +385,33 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                 if constexpr (t >= d0 && t < d0 + sp * (F_PPW + 1) && (t - d0) % sp == 0)
                     issue_piece(s + 2, (t - d0) / sp);
             }
-            if constexpr (LAG == 1 && t == 0) seed(accA, cur, 0);          // used from step 8 on
-            // the other accumulator is free once its epilogue (below) has run: seed it early
-            if constexpr ((LAG == 0 && t == 4) || (LAG == 1 && t == 12)) seed(accB, cur, 1);
-            if constexpr (LAG == 0 && t == 28) seed(accA, nxt, 0);          // next interval's block 0
+            if constexpr (DB) {
+                if constexpr (LAG == 1 && t == 0) seed(accA, cur, 0);          // used from step 8 on
+                // the other accumulator is free once its epilogue (below) has run: seed it early
+                if constexpr ((LAG == 0 && t == 4) || (LAG == 1 && t == 12)) seed(accB, cur, 1);
+                if constexpr (LAG == 0 && t == 28) seed(accA, nxt, 0);          // next interval's block 0
+            } else {
+                // single accumulator set: a tile is seeded right where it starts
+                if constexpr (b == 0) seed(accA, cur, blk);
+            }
             // (LAG 1, very first interval: steps 0..7 chew on a not-yet-written ring slot; their
             //  accumulator is discarded below and re-seeded at step 12)
-            if constexpr (blk == 0) mma_all(accA, fr[t % RING], std::integral_constant<int, b>{});
+            if constexpr (blk == 0 || !DB) mma_all(accA, fr[t % RING], std::integral_constant<int, b>{});
             else mma_all(accB, fr[t % RING], std::integral_constant<int, b>{});
             // deferred epilogues: one step into the following tile
-            if constexpr ((LAG == 0 && t == 1) || (LAG == 1 && t == 9)) {
-                if (!first) epilogue(accB, blk0_global - 1);                 // previous slot's block 1
+            if constexpr (DB) {
+                if constexpr ((LAG == 0 && t == 1) || (LAG == 1 && t == 9)) {
+                    if (!first) epilogue(accB, blk0_global - 1);                 // previous slot's block 1
+                }
+                if constexpr ((LAG == 0 && t == 17) || (LAG == 1 && t == 25)) epilogue(accA, blk0_global);
+            } else if constexpr (b == F_STEPS - 1) {
+                // single accumulator set: the tile's epilogue right at its end
+                if constexpr (LAG == 1 && t < 8) {
+                    if (!first) epilogue(accA, blk0_global - 1);
+                } else {
+                    epilogue(accA, blk0_global + blk);
+                }
             }
-            if constexpr ((LAG == 0 && t == 17) || (LAG == 1 && t == 25)) epilogue(accA, blk0_global);
 #ifndef NNS_F_NOSCHED
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -387,7 +424,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
 #ifdef NNS_F_PRIO
     if (lag) __builtin_amdgcn_s_setprio(1);
 #endif
-    auto ring = [&](int s) { return smem + ((s + F_D) & (F_D - 1)) * F_SLOT_BYTES; };
+    auto ring = [&](int s) __attribute__((always_inline)) { return smem + ((s + F_D) & (F_D - 1)) * F_SLOT_BYTES; };
     static_assert((F_D & (F_D - 1)) == 0, "ring depth must be a power of two");
 
     // prologue: slots 0 and 1 in flight; confirm slot 0; start interval 0's first fragments
@@ -396,11 +433,13 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(F_PPW + 1) : "memory");
     __builtin_amdgcn_s_barrier();
     // (LAG 1 reads ring slot -1 here: garbage in, discarded — see the interval)
-    static_for<PF>([&](auto t) {
+    static_for<PF>([&](auto t) __attribute__((always_inline)) {
         constexpr int tt = decltype(t)::value;
         fr[tt % RING] = *frag_ptr(lag ? ring(-1) : ring(0), lag ? 1 : 0, lag ? 8 + tt : tt);
     });
-    if (!lag) seed(accA, ring(0), 0);
+    if constexpr (DB) {
+        if (!lag) seed(accA, ring(0), 0);
+    }
     for (int s = 0; s < ns; ++s) {
         if constexpr ((kAblate & 1) == 0) {
             // my share of slot s+1 has landed (issued an interval ago; the only DMA in flight)
@@ -415,13 +454,15 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         const int last_blk1 = (slot0 + ns - 1) * F_SB + 1;
         if (lag) {   // the lagging half block of the last slot; its first PF fragments are in the ring
             const char *lastp = ring(ns - 1);
-            static_for<F_STEPS / 2>([&](auto tc_) {
+            static_for<F_STEPS / 2>([&](auto tc_) __attribute__((always_inline)) {
                 constexpr int t = decltype(tc_)::value;
                 if constexpr (t + PF < F_STEPS / 2) fr[(t + PF) % RING] = *frag_ptr(lastp, 1, 8 + t + PF);
-                mma_all(accB, fr[t % RING], std::integral_constant<int, 8 + t>{});
+                if constexpr (DB) mma_all(accB, fr[t % RING], std::integral_constant<int, 8 + t>{});
+                else mma_all(accA, fr[t % RING], std::integral_constant<int, 8 + t>{});
             });
         }
-        epilogue(accB, last_blk1);
+        if constexpr (DB) epilogue(accB, last_blk1);
+        else if (lag) epilogue(accA, last_blk1);
     }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) a.counts[(lblk0 + qb) * 64 + lane] = cnt[qb];
