@@ -302,13 +302,17 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             for (int r = 0; r < 16; ++r) {
                 const float x = acc[r];
                 if (x <= thr[qb] && x < __builtin_inff()) {
-                    if (cnt[qb] < kCandCap) {
-                        CandEntry e;
-                        e.s = x;
-                        e.j = jbase + (r & 3) + 8 * (r >> 2);
-                        list[qb][cnt[qb] * 64] = e;
+                    const int pos = cnt[qb] & (kCandCap - 1);
+                    if ((cnt[qb] & kCandCountMask) >= kCandCap) {
+                        // ring wrap: the slot's old entry may only be dropped if it is above the
+                        // current threshold (then it can never be within tau of the final minimum)
+                        if (list[qb][pos * 64].s <= thr[qb]) cnt[qb] |= kCandOverflow;
                     }
-                    ++cnt[qb];   // > kCandCap marks overflow: K5 sends the query to the exact scan
+                    CandEntry e;
+                    e.s = x;
+                    e.j = jbase + (r & 3) + 8 * (r >> 2);
+                    list[qb][pos * 64] = e;
+                    ++cnt[qb];
                     if (x < m1[qb]) {
                         m1[qb] = x;
                         thr[qb] = x + tau_of(tc[qb], x) * 1.002f;   // a hair wider than K5's own tau

@@ -90,10 +90,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(
                 // [split][query block][entry][lane], lane = 32h + (i & 31)
                 const size_t lblk = (size_t)s * (m_pad / 32) + (i >> 5);
                 const int ln = 32 * h + (i & 31);
-                const int c = counts[lblk * 64 + ln];
-                if (c > kCandCap) fallback = true;
+                const int cw = counts[lblk * 64 + ln];
+                if (cw & kCandOverflow) fallback = true;
+                const int c = (cw & kCandCountMask) < kCandCap ? (cw & kCandCountMask) : kCandCap;
                 const CandEntry *l = lists + lblk * (kCandCap * 64) + ln;
-                for (int e = 0; e < c && e < kCandCap; ++e) a = fminf(a, l[e * 64].s);
+                for (int e = 0; e < c; ++e) a = fminf(a, l[e * 64].s);
             }
     }
     if (!(a < __builtin_inff())) fallback = true;
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(
             for (int h = 0; h < 2; ++h) {
                 const size_t lblk = (size_t)s * (m_pad / 32) + (i >> 5);
                 const int ln = 32 * h + (i & 31);
-                const int c = counts[lblk * 64 + ln];
+                const int cw = counts[lblk * 64 + ln] & kCandCountMask;
+                const int c = cw < kCandCap ? cw : kCandCap;
                 const CandEntry *l = lists + lblk * (kCandCap * 64) + ln;
                 for (int e = 0; e < c; ++e) {
                     const CandEntry ce = l[e * 64];
@@ -152,10 +154,11 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
         const int s = l >> 1, h = l & 1;
         const size_t lblk = (size_t)s * (m_pad / 32) + (i >> 5);
         const int ln = 32 * h + (i & 31);
-        const int c = counts[lblk * 64 + ln];
-        if (c > kCandCap) over = 1;
+        const int cw = counts[lblk * 64 + ln];
+        if (cw & kCandOverflow) over = 1;
+        const int c = (cw & kCandCountMask) < kCandCap ? (cw & kCandCountMask) : kCandCap;
         const CandEntry *lp = lists + lblk * (kCandCap * 64) + ln;
-        for (int e = 0; e < c && e < kCandCap; ++e) a = fminf(a, lp[e * 64].s);
+        for (int e = 0; e < c; ++e) a = fminf(a, lp[e * 64].s);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -174,7 +177,8 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
             const int s = l >> 1, h = l & 1;
             const size_t lblk = (size_t)s * (m_pad / 32) + (i >> 5);
             const int ln = 32 * h + (i & 31);
-            const int c = counts[lblk * 64 + ln];
+            const int cw = counts[lblk * 64 + ln] & kCandCountMask;
+            const int c = cw < kCandCap ? cw : kCandCap;
             const CandEntry *lp = lists + lblk * (kCandCap * 64) + ln;
             for (int e = 0; e < c; ++e) {
                 const CandEntry ce = lp[e * 64];

@@ -80,10 +80,14 @@ struct __attribute__((aligned(8))) CandEntry {
     float s;
     int j;
 };
-// capacity of one lane's private candidate list (per split, query, lane half); a lane
-// collects ~ln(refs it sees) records, so 64 overflows only on adversarial inputs — an
-// overflowing query is re-ranked by the exact scan instead.
-constexpr int kCandCap = 64;
+// capacity of one lane's private candidate list (per split, query, lane half).  The list
+// is a RING: a lane collects ~ln(refs it sees) records, and when more than kCandCap were
+// appended (monotone inputs) the oldest entry is overwritten — provably harmless when its
+// score is above the lane's current threshold (thresholds only shrink), otherwise the
+// overflow bit is set and the query is re-ranked by the exact scan instead.
+constexpr int kCandCap = 64;                 // power of two
+constexpr int kCandOverflow = 1 << 30;       // bit of the per-list count word
+constexpr int kCandCountMask = kCandOverflow - 1;
 
 // tau(a) = c0 + c1 * max(a + x2, 0): the margin within which a filter score cannot be
 // ordered against V0's fp32 distances (derivation: finalize.hip).  Shared by K3/K4 (which

@@ -123,9 +123,10 @@ def test_filter_ragged_shapes(pkg, orc, shape):
     _check(pkg, orc, q, r, paths=("mfma",), shards=(1, 2))
 
 
-def test_filter_sorted_refs_overflow_lists(pkg, orc):
-    """Refs ordered so that every ref is a new record for the query (monotone approach):
-    the per-lane candidate lists overflow and the exact scan must take over."""
+def test_filter_sorted_refs_ring_lists(pkg, orc):
+    """Refs ordered so that every ref is a new record for the query (monotone approach): the
+    per-lane candidate lists wrap around (old records fall above the shrinking threshold and
+    are overwritten) — parity must hold without needing the exact scan for every query."""
     rng = np.random.default_rng(77)
     k, n = 64, 40000      # 256 ref-range splits -> ~78 refs per lane per split > the list capacity
     base = rng.random((1, k), dtype=np.float32)
@@ -138,7 +139,25 @@ def test_filter_sorted_refs_overflow_lists(pkg, orc):
     ix = pkg.Index(torch.from_numpy(r).cuda(), path="mfma")
     ix.search(torch.from_numpy(q).cuda())
     st = ix.stats()
-    assert st["ambiguous"] >= 1, st
+    assert st["path"] == 2 and st["ambiguous"] < q.shape[0], st
+    ix.close()
+
+
+def test_filter_true_list_overflow_falls_back(pkg, orc):
+    """80000 exact duplicates of the nearest ref: every copy is a live candidate,
+    the ring lists genuinely overflow, and the exact scan must return the LOWEST duplicate."""
+    rng = np.random.default_rng(78)
+    k = 128
+    base = rng.random((2000, k), dtype=np.float32)
+    hot = rng.random((1, k), dtype=np.float32)
+    r = np.concatenate([base[:700], np.repeat(hot, 80000, axis=0), base[700:]])
+    q = np.concatenate([hot + rng.normal(0, 1e-4, (24, k)).astype(np.float32), rng.random((40, k), dtype=np.float32)])
+    _check(pkg, orc, q, r, paths=("mfma",), shards=(1, 2))
+    ix = pkg.Index(torch.from_numpy(r).cuda(), path="mfma")
+    idx = ix.search(torch.from_numpy(q).cuda())
+    st = ix.stats()
+    assert st["ambiguous"] >= 24, st
+    assert (idx[:24].cpu().numpy() == 700).all()
     ix.close()
 
 
