@@ -125,8 +125,14 @@ __device__ __forceinline__ nns_key wave_min_key(nns_key v)
 // one LDS access, no bank conflict) against QPL queries held in registers.  (Reading the
 // wave-uniform refs through the scalar cache instead thrashes it: 8 co-resident
 // workgroups stream 8 different ref ranges through 16 KiB.)
-constexpr int K1A_QPL = 2;          // queries per lane
+#ifndef NNS_K1A_QPL
+#define NNS_K1A_QPL 2
+#endif
+constexpr int K1A_QPL = NNS_K1A_QPL;   // queries per lane
 constexpr int K1A_LDS_FLOATS = 4096;   // 16 KiB ref tile
+#ifndef NNS_K1A_WAVES
+#define NNS_K1A_WAVES 8192   // target number of waves in the grid (8 per SIMD)
+#endif
 
 template <int K>
 struct K1aChunk {
@@ -264,7 +270,7 @@ static int launch_k1a(int m, int n, const float *q, const float *r, int64_t base
     const int qtiles = divup(m, 256 * K1A_QPL);
     const int qwaves = divup(m, 64 * K1A_QPL);
     // enough waves to fill 256 CUs x 4 SIMDs a few times over, >= 256 refs per split
-    int splits = divup(8192, qwaves);
+    int splits = divup(NNS_K1A_WAVES, qwaves);
     const int max_splits = divup(n, 256);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -611,7 +617,7 @@ size_t exact_workspace_keys(int k, int m, int n)
 {
     // upper bound of splits * m for K1a (see launch_k1a)
     if (m < 64 || !(k == 1 || k == 2 || k == 3 || k == 4 || k == 8 || k == 16)) return 0;
-    int splits = divup(8192, divup(m, 64 * K1A_QPL));
+    int splits = divup(NNS_K1A_WAVES, divup(m, 64 * K1A_QPL));
     const int max_splits = divup(n, 256);
     if (splits > max_splits) splits = max_splits;
     if (splits < 2) return 0;

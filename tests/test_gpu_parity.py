@@ -389,3 +389,23 @@ def test_offset_clouds_need_centring(pkg, orc):
         q = (off + spread * rng.random((130, 128))).astype(np.float32)
         r = (off + spread * rng.random((6000, 128))).astype(np.float32)
         _check(pkg, orc, q, r, paths=("mfma",), shards=(1, 3))
+
+
+@pytest.mark.timeout(600)
+def test_midsize_all_queries_vs_oracle(pkg, orc):
+    """Every query of a mid-size problem (fp32 4096 x 262144 x 128, bf16 2048 x 131072 x 256)
+    against the oracle over all refs — the largest shapes the CPU oracle finishes in seconds."""
+    m, n, k = 4096, 262144, 128
+    q = orc.rng_uniform(m * k, 77, 0).reshape(m, k)
+    r = orc.rng_uniform(n * k, 77, m * k).reshape(n, k)
+    want_idx, want_dist = orc.v0_search(q, r, threads=16)
+    idx, dist = pkg.search(q, r, return_distances=True)
+    assert np.array_equal(idx, want_idx)
+    assert np.array_equal(_bits(dist), _bits(want_dist))
+    m, n, k = 2048, 131072, 256
+    q = orc.rng_uniform(m * k, 78, 0).reshape(m, k)
+    r = orc.rng_uniform(n * k, 78, m * k).reshape(n, k)
+    want_idx, want_dist = orc.v0_search(orc.round_bf16(q), orc.round_bf16(r), threads=16)
+    idx, dist = pkg.search_bf16(pkg.to_bf16_bits(q), pkg.to_bf16_bits(r), return_distances=True)
+    assert np.array_equal(idx, want_idx)
+    assert np.array_equal(_bits(dist), _bits(want_dist))
