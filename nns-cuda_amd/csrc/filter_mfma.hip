@@ -424,7 +424,11 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
 
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+#ifdef NNS_F_NOLAG
+    const bool lag = false;   // diagnostic: SIMD partners in lock-step
+#else
     const bool lag = wave >= F_NW / 2;   // wave-uniform
+#endif
 #ifdef NNS_F_PRIO
     if (lag) __builtin_amdgcn_s_setprio(1);
 #endif
