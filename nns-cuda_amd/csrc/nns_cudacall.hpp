@@ -31,4 +31,20 @@ inline void cudaCall(int k,            // dimensionality
     }
 }
 
+// The V8/V9 flavour (core.cu:761-853, 965-1057): same signature, refs sharded over every
+// visible GPU (one host thread per GPU, RCCL min all-reduce of packed keys), with the
+// reference's own small-problem fallback to one GPU (core.cu:775-777).
+inline void cudaCallAllGpus(int k, int m, int n, float *s_points, float *r_points, int **results)
+{
+    int *tmp = (int *)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+    const int rc = tmp ? nns_search_f32_multi(k, m, n, s_points, r_points, tmp, nullptr, 0, NNS_PATH_AUTO)
+                       : NNS_ERR_NOMEM;
+    if (rc != NNS_OK) {
+        printf("Error: %s:%d, ", __FILE__, __LINE__);
+        printf("code:%d, reason: %s (%s) \n", rc, nns_strerror(rc), nns_last_error());
+        exit(1);
+    }
+    *results = tmp;
+}
+
 }  // namespace mi355x

@@ -12,7 +12,7 @@
 // It adds an FNV-1a digest of the result indices per sample so a run can be compared with
 // the oracle's digests (tests/test_driver.py) — the driver itself contains no CPU search.
 //
-// usage: nns_driver [--seed S] [--samples a,b,...] [--repeat R] [--no-warmup]
+// usage: nns_driver [--seed S] [--samples a,b,...] [--repeat R] [--no-warmup] [--all-gpus]
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -70,12 +70,14 @@ int main(int argc, char **argv)
     unsigned seed = 1000;   // main.cu:54
     int repeat = 1;
     bool warmup = true;
+    bool all_gpus = false;   // mi355x::cudaCallAllGpus (the V8/V9 analogue) instead of one GPU
     bool selected[kNumShapes];
     for (int i = 0; i < kNumShapes; ++i) selected[i] = true;
     for (int a = 1; a < argc; ++a) {
         if (!strcmp(argv[a], "--seed") && a + 1 < argc) seed = (unsigned)strtoul(argv[++a], nullptr, 10);
         else if (!strcmp(argv[a], "--repeat") && a + 1 < argc) repeat = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--no-warmup")) warmup = false;
+        else if (!strcmp(argv[a], "--all-gpus")) all_gpus = true;
         else if (!strcmp(argv[a], "--samples") && a + 1 < argc) {
             for (int i = 0; i < kNumShapes; ++i) selected[i] = false;
             char *tok = strtok(argv[++a], ",");
@@ -85,12 +87,13 @@ int main(int argc, char **argv)
                 tok = strtok(nullptr, ",");
             }
         } else {
-            fprintf(stderr, "usage: %s [--seed S] [--samples a,b,...] [--repeat R] [--no-warmup]\n", argv[0]);
+            fprintf(stderr, "usage: %s [--seed S] [--samples a,b,...] [--repeat R] [--no-warmup] [--all-gpus]\n", argv[0]);
             return 2;
         }
     }
 
-    void (*func)(int, int, int, float *, float *, int **) = &mi355x::cudaCall;   // main.cu:7
+    void (*func)(int, int, int, float *, float *, int **) =                      // main.cu:7
+        all_gpus ? &mi355x::cudaCallAllGpus : &mi355x::cudaCall;
 
     if (warmup) {   // explicit stand-in for the reference's WarmUP static (core.cu:1900-1933)
         float q[1] = {0.5f}, r[4] = {0.1f, 0.2f, 0.6f, 0.9f};

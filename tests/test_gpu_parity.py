@@ -409,3 +409,56 @@ def test_midsize_all_queries_vs_oracle(pkg, orc):
     idx, dist = pkg.search_bf16(pkg.to_bf16_bits(q), pkg.to_bf16_bits(r), return_distances=True)
     assert np.array_equal(idx, want_idx)
     assert np.array_equal(_bits(dist), _bits(want_dist))
+
+
+def test_c2_shape_all_queries(pkg, orc):
+    """BASELINE config C2 at full size (4096 x 65536 x 3): every query vs the oracle."""
+    m, n, k = 4096, 65536, 3
+    q = orc.rng_uniform(m * k, 1000, 0).reshape(m, k)
+    r = orc.rng_uniform(n * k, 1000, m * k).reshape(n, k)
+    want_idx, want_dist = orc.v0_search(q, r, threads=16)
+    idx, dist = pkg.search(q, r, return_distances=True)
+    assert np.array_equal(idx, want_idx) and np.array_equal(_bits(dist), _bits(want_dist))
+
+
+@pytest.mark.timeout(900)
+def test_c4_shape_on_one_gpu_by_shards(pkg, orc):
+    """BASELINE config C4 (65536 x 8388608 x 128, refs sharded 8 ways) rehearsed on ONE GPU: the 8
+    shards are searched one after another with their index_base and merged with nns_keys_min —
+    exactly what 8 ranks + the min all-reduce compute.  Checked: planted exact matches in every
+    shard, sampled queries against the oracle over all 8M refs, index range."""
+    m, n, k, shards = 65536, 8388608, 128, 8
+    q = torch.empty((m, k), dtype=torch.float32, device="cuda")
+    pkg.fill_uniform(q, 1000, 0)
+    per = n // shards
+    keys = None
+    r_host = np.empty((n, k), dtype=np.float32)
+    planted_q = np.arange(shards * 16) * 401
+    planted_r = np.empty(shards * 16, dtype=np.int64)
+    for s in range(shards):
+        r = torch.empty((per, k), dtype=torch.float32, device="cuda")
+        pkg.fill_uniform(r, 1000, m * k + s * per * k)       # the bench's global ref stream
+        for t in range(16):                                    # plant 16 queries per shard
+            qi = planted_q[s * 16 + t]
+            lj = (t * 65537 + 11) % per
+            r[lj] = q[qi]
+            planted_r[s * 16 + t] = s * per + lj
+        r_host[s * per:(s + 1) * per] = r.cpu().numpy()
+        ix = pkg.Index(r, index_base=s * per)
+        ks = ix.search_keys(q)
+        if keys is None:
+            keys = ks.clone()
+        else:
+            pkg.keys_min(keys, ks)
+        torch.cuda.synchronize()
+        ix.close()
+        del r
+    idx, dist = pkg.keys_unpack(keys, return_distances=True)
+    idx_h, dist_h = idx.cpu().numpy(), dist.cpu().numpy()
+    assert idx_h.min() >= 0 and idx_h.max() < n
+    assert np.array_equal(idx_h[planted_q], planted_r.astype(np.int32))
+    assert (dist_h[planted_q] == 0).all()
+    sel = np.random.default_rng(4).choice(m, 24, replace=False)
+    want_idx, want_dist = orc.v0_search(q[torch.from_numpy(sel).cuda()].cpu().numpy(), r_host, threads=16)
+    assert np.array_equal(idx_h[sel], want_idx)
+    assert np.array_equal(_bits(dist_h[sel]), _bits(want_dist))
