@@ -19,16 +19,6 @@ for W in c3 c5; do
   done
 done
 timeout -k 10 300 ./nns-cuda_amd/nns_driver --repeat 3 > $OUT/driver.txt 2>&1
-timeout -k 10 300 python - > $OUT/wholecall_c3.txt 2>&1 <<'PY'
-import sys, time, numpy as np
-sys.path.insert(0, ".")
-import __graft_entry__ as g
-pkg = g.load_package(); orc = g.load_oracle()
-m, n, k = 65536, 1048576, 128
-q = orc.rng_uniform(m * k, 1000, 0).reshape(m, k); r = orc.rng_uniform(n * k, 1000, m * k).reshape(n, k)
-for rep in range(3):
-    t0 = time.perf_counter(); idx = pkg.cudaCall(k, m, n, q, r); dt = time.perf_counter() - t0
-    print(f"whole call nns_search_f32 (malloc + H2D of {(q.nbytes + r.nbytes) / 2**20:.0f} MiB pageable + search + D2H + free): {dt * 1e3:.1f} ms -> {m * n / dt:.3e} pairs/s")
-PY
+timeout -k 10 300 python tools/wholecall_c3.py > $OUT/wholecall_c3.txt 2>&1
 cat $OUT/wholecall_c3.txt | grep -v amdgpu
 ls $OUT
