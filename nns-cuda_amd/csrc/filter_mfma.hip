@@ -545,9 +545,28 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g)
     g->n_pad = divup(n, slot_pts) * slot_pts;
     g->total_slots = g->n_pad / slot_pts;
     g->qgroups = g->m_pad / qw;
-    // one 8-wave workgroup is resident per CU (99 KiB of LDS): cover the 256 CUs
+    // One 8-wave workgroup is resident per CU (132 KiB of LDS), so the grid runs in rounds of
+    // 256 workgroups and a round that is mostly empty costs as much as a full one.  Choose the
+    // number of ref-range splits that minimises rounds x (work per workgroup), i.e.
+    // ceil(qgroups * s / 256) / s, with a small per-split charge (prologue, lists, merge) and a
+    // cap on the candidate-list memory (1 KiB per query per split).
     int splits = 1;
-    if (g->qgroups < 256) splits = divup(256, g->qgroups);
+    {
+        const int64_t list_cap = (int64_t)2 << 30;
+        double best_cost = 1e30;
+        for (int sp = 1; sp <= 64; ++sp) {
+            if (sp > g->total_slots) break;
+            if (sp > 1 && (int64_t)sp * g->m_pad * 1024 > list_cap) break;
+            const int rounds = divup(g->qgroups * sp, 256);
+            const double cost = (double)rounds / sp * (1.0 + 0.004 * sp);
+            if (cost < best_cost - 1e-12) {
+                best_cost = cost;
+                splits = sp;
+            }
+        }
+        // very few queries: more splits than the scan above tries, to cover all CUs
+        if (g->qgroups * splits < 256) splits = divup(256, g->qgroups);
+    }
     if (splits > g->total_slots) splits = g->total_slots;
     if (splits > 65535) splits = 65535;
     g->slots_per_split = divup(g->total_slots, splits);
@@ -606,7 +625,7 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
         if (!ghz.empty())
             fprintf(stderr, "[nns] filter in-kernel clock: median %.3f GHz (min %.3f, max %.3f) over %zu workgroups\n",
                     ghz[ghz.size() / 2], ghz.front(), ghz.back(), ghz.size());
-        hipFree(a.stamps);
+        (void)hipFree(a.stamps);
     }
     return rc;
 }

@@ -136,19 +136,19 @@ int nns_index_destroy(nns_index *ix)
 {
     if (!ix) return NNS_OK;
     (void)hipSetDevice(ix->device);
-    hipFree(ix->rimg);
-    hipFree(ix->rnorm);
-    hipFree(ix->mean);
-    hipFree(ix->mean_ws);
-    hipFree(ix->scal);
-    hipFree(ix->qimg);
-    hipFree(ix->qnorm);
-    hipFree(ix->lists);
-    hipFree(ix->counts);
-    hipFree(ix->amb_list);
-    hipFree(ix->exact_ws);
+    (void)hipFree(ix->rimg);
+    (void)hipFree(ix->rnorm);
+    (void)hipFree(ix->mean);
+    (void)hipFree(ix->mean_ws);
+    (void)hipFree(ix->scal);
+    (void)hipFree(ix->qimg);
+    (void)hipFree(ix->qnorm);
+    (void)hipFree(ix->lists);
+    (void)hipFree(ix->counts);
+    (void)hipFree(ix->amb_list);
+    (void)hipFree(ix->exact_ws);
     if (ix->ev_valid)
-        for (int i = 0; i < EV_COUNT; ++i) hipEventDestroy(ix->ev[i]);
+        for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ix->ev[i]);
     delete ix;
     return NNS_OK;
 }
@@ -216,9 +216,9 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
                 rc = NNS_ERR_NOMEM;
                 break;
             }
-            if (ix->profile) hipEventRecord(ix->ev[EV_R0], st);
+            if (ix->profile) (void)hipEventRecord(ix->ev[EV_R0], st);
             if ((rc = prep_refs(ix, st)) != NNS_OK) break;
-            if (ix->profile) hipEventRecord(ix->ev[EV_R1], st);
+            if (ix->profile) (void)hipEventRecord(ix->ev[EV_R1], st);
             // index build is synchronous: learn whether the refs void the error bound
             DevScalars h{};
             if (hipMemcpyAsync(&h, ix->scal, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -256,9 +256,9 @@ int nns_index_refresh(nns_index *ix, void *stream)
     NNS_TRY(ensure_device_ok(ix->device));
     if (ix->path != NNS_PATH_MFMA) return NNS_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (ix->profile) hipEventRecord(ix->ev[EV_R0], st);
+    if (ix->profile) (void)hipEventRecord(ix->ev[EV_R0], st);
     NNS_TRY(prep_refs(ix, st));
-    if (ix->profile) hipEventRecord(ix->ev[EV_R1], st);
+    if (ix->profile) (void)hipEventRecord(ix->ev[EV_R1], st);
     return NNS_OK;
 }
 
@@ -270,10 +270,10 @@ static int ensure_query_ws(nns_index *ix, int m)
     ix->geom = gq;   // same kt / n_pad / total_slots; m-dependent grid now filled in
     (void)g;
     if (gq.m_pad > ix->m_cap) {
-        hipFree(ix->qimg);
-        hipFree(ix->qnorm);
-        hipFree(ix->amb_list);
-    hipFree(ix->exact_ws);
+        (void)hipFree(ix->qimg);
+        (void)hipFree(ix->qnorm);
+        (void)hipFree(ix->amb_list);
+    (void)hipFree(ix->exact_ws);
         ix->qimg = nullptr;
         ix->qnorm = nullptr;
         ix->amb_list = nullptr;
@@ -288,8 +288,8 @@ static int ensure_query_ws(nns_index *ix, int m)
     }
     const size_t need = (size_t)gq.splits * gq.m_pad * 2;   // lane-lists
     if (need > ix->lists_cap) {
-        hipFree(ix->lists);
-        hipFree(ix->counts);
+        (void)hipFree(ix->lists);
+        (void)hipFree(ix->counts);
         ix->lists = nullptr;
         ix->counts = nullptr;
         ix->lists_cap = 0;
@@ -322,7 +322,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
     // is then HBM-bound and the exact lane-per-ref kernel is the faster path (AUTO only).
     const bool tiny = (ix->flags & NNS_PATH_MASK) == NNS_PATH_AUTO && m < kTinyM;
     if (ix->path != NNS_PATH_MFMA || ix->refs_bad || tiny) {
-        if (prof) hipEventRecord(ix->ev[EV_BEGIN], st);
+        if (prof) (void)hipEventRecord(ix->ev[EV_BEGIN], st);
         if (bf16)
             NNS_TRY(launch_exact_search_bf16(ix->k, m, ix->n, (const uint16_t *)q_dev, (const uint16_t *)ix->r_dev,
                                              ix->base, keys_dev, st));
@@ -330,7 +330,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
         {
             const size_t need = exact_workspace_keys(ix->k, m, ix->n);
             if (need > ix->exact_ws_keys) {
-                hipFree(ix->exact_ws);
+                (void)hipFree(ix->exact_ws);
                 ix->exact_ws = nullptr;
                 ix->exact_ws_keys = 0;
                 if (hipMalloc(&ix->exact_ws, need * sizeof(nns_key)) == hipSuccess) ix->exact_ws_keys = need;
@@ -339,7 +339,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
             NNS_TRY(launch_exact_search(ix->k, m, ix->n, (const float *)q_dev, (const float *)ix->r_dev, ix->base,
                                         keys_dev, ix->exact_ws, ix->exact_ws_keys, st));
         }
-        if (prof) hipEventRecord(ix->ev[EV_END], st);
+        if (prof) (void)hipEventRecord(ix->ev[EV_END], st);
         ix->last_path = NNS_PATH_EXACT;
         ix->searched = true;
         return NNS_OK;
@@ -347,7 +347,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
 
     NNS_TRY(ensure_query_ws(ix, m));
     const FilterGeom &g = ix->geom;
-    if (prof) hipEventRecord(ix->ev[EV_BEGIN], st);
+    if (prof) (void)hipEventRecord(ix->ev[EV_BEGIN], st);
     // reset the per-search scalars (q max-abs, ambiguous count); keep the ref-side ones
     NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned), st));
     NNS_HIP(hipMemsetAsync(&ix->scal->amb_count, 0, sizeof(int), st));
@@ -357,12 +357,12 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
     else
         NNS_TRY(launch_prep_image(ix->k, g.kt, m, g.m_pad, (const float *)q_dev, ix->mean, 1.0f, 0.0f,
                                   (float *)ix->qimg, ix->qnorm, nullptr, &ix->scal->q_maxabs_bits, st));
-    if (prof) hipEventRecord(ix->ev[EV_QPREP], st);
+    if (prof) (void)hipEventRecord(ix->ev[EV_QPREP], st);
     NNS_TRY(launch_filter(g, ix->qimg, ix->rimg, ix->rnorm, ix->qnorm, ix->scal, ix->lists, ix->counts, st));
-    if (prof) hipEventRecord(ix->ev[EV_FILTER], st);
+    if (prof) (void)hipEventRecord(ix->ev[EV_FILTER], st);
     NNS_TRY(launch_finalize(g, ix->k, m, ix->n, q_dev, ix->r_dev, ix->lists, ix->counts, ix->qnorm,
                             ix->scal, ix->base, keys_dev, ix->amb_list, st));
-    if (prof) hipEventRecord(ix->ev[EV_FINAL], st);
+    if (prof) (void)hipEventRecord(ix->ev[EV_FINAL], st);
     if (bf16)
         NNS_TRY(launch_exact_listed_bf16(ix->k, ix->n, (const uint16_t *)q_dev, (const uint16_t *)ix->r_dev,
                                          ix->amb_list, &ix->scal->amb_count, m, ix->base, keys_dev, st));
@@ -370,8 +370,8 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
         NNS_TRY(launch_exact_listed(ix->k, ix->n, (const float *)q_dev, (const float *)ix->r_dev, ix->amb_list,
                                     &ix->scal->amb_count, m, ix->base, keys_dev, st));
     if (prof) {
-        hipEventRecord(ix->ev[EV_RERANK], st);
-        hipEventRecord(ix->ev[EV_END], st);
+        (void)hipEventRecord(ix->ev[EV_RERANK], st);
+        (void)hipEventRecord(ix->ev[EV_END], st);
     }
     ix->last_path = NNS_PATH_MFMA;
     ix->searched = true;
@@ -459,7 +459,7 @@ int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const fl
     if (rc == NNS_OK && hipMemcpy(out, d + 2 * na + 32, 1024 * 4, hipMemcpyDeviceToHost) != hipSuccess)
         rc = NNS_ERR_HIP;
     if (rc == NNS_ERR_HIP) set_error("nns_selftest_mfma: %s", hipGetErrorString(hipGetLastError()));
-    hipFree(d);
+    (void)hipFree(d);
     return rc;
 }
 
@@ -532,12 +532,12 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             rc = NNS_ERR_HIP;
         }
     } while (0);
-    hipFree(q_d);
-    hipFree(r_d);
-    hipFree(keys);
-    hipFree(keys_tmp);
-    hipFree(idx_d);
-    hipFree(dist_d);
+    (void)hipFree(q_d);
+    (void)hipFree(r_d);
+    (void)hipFree(keys);
+    (void)hipFree(keys_tmp);
+    (void)hipFree(idx_d);
+    (void)hipFree(dist_d);
     return rc;
 }
 

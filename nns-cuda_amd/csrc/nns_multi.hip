@@ -167,7 +167,7 @@ extern "C" int nns_search_f32_multi(int k, int m, int n, const float *s_points, 
                     (void)hipSetDevice(jobs[g].device);
                     if (hipDeviceSynchronize() != hipSuccess) ok = false;
                 }
-                for (int g = 0; g < G; ++g) api.CommDestroy(comms[g]);
+                for (int g = 0; g < G; ++g) (void)api.CommDestroy(comms[g]);
                 reduced = ok;
             }
         }
@@ -201,15 +201,15 @@ extern "C" int nns_search_f32_multi(int k, int m, int n, const float *s_points, 
             (hipMemcpy(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
              (dist_out && hipMemcpy(dist_out, dist_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)))
             rc = NNS_ERR_HIP;
-        hipFree(idx_d);
-        hipFree(dist_d);
+        (void)hipFree(idx_d);
+        (void)hipFree(dist_d);
         if (rc == NNS_ERR_HIP) set_error("nns_search_f32_multi: merge/unpack failed: %s", hipGetErrorString(hipGetLastError()));
     }
     for (int g = 0; g < G; ++g) {
         (void)hipSetDevice(jobs[g].device);
-        hipFree(jobs[g].q_d);
-        hipFree(jobs[g].r_d);
-        hipFree(jobs[g].keys);
+        (void)hipFree(jobs[g].q_d);
+        (void)hipFree(jobs[g].r_d);
+        (void)hipFree(jobs[g].keys);
     }
     (void)hipSetDevice(0);
     return rc;

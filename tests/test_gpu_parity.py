@@ -462,3 +462,13 @@ def test_c4_shape_on_one_gpu_by_shards(pkg, orc):
     want_idx, want_dist = orc.v0_search(q[torch.from_numpy(sel).cuda()].cpu().numpy(), r_host, threads=16)
     assert np.array_equal(idx_h[sel], want_idx)
     assert np.array_equal(_bits(dist_h[sel]), _bits(want_dist))
+
+
+def test_awkward_query_counts_balance(pkg, orc):
+    """Query counts just past a workgroup/round boundary (the split chooser must keep the grid
+    balanced; results must not depend on the split count)."""
+    rng = np.random.default_rng(123)
+    r = rng.random((30000, 128), dtype=np.float32)
+    for m in (513, 1537, 5000):
+        q = rng.random((m, 128), dtype=np.float32)
+        _check(pkg, orc, q, r, paths=("mfma",), shards=(1,))
