@@ -64,7 +64,7 @@ enum {
 
 /* path selection flags (nns_index_create / nns_search_f32_ex) */
 enum {
-    NNS_PATH_AUTO = 0,   /* MFMA filter for k >= 32, exact VALU kernels below */
+    NNS_PATH_AUTO = 0,   /* MFMA filter for 8 <= k <= 128 (bf16: 32..256) and >= 64 queries, exact kernels otherwise */
     NNS_PATH_EXACT = 1,  /* exact per-pair kernels only (V1..V9 arithmetic re-expressed) */
     NNS_PATH_MFMA = 2,   /* -2*Q*R^T MFMA filter + exact re-rank (k padded to the tile K) */
     NNS_PATH_MASK = 3,
@@ -193,6 +193,12 @@ int nns_device_count(void);
 const char *nns_strerror(int status);
 const char *nns_last_error(void); /* thread-local detail of the last failure */
 int nns_version(void);            /* major * 1000 + minor */
+/* The library parks freed device workspaces (queries/refs staging, tile images, candidate
+ * lists) in a per-device pool instead of returning them to the runtime on every call — the
+ * reference allocates and frees on every cudaCall (core.cu:793-802).  nns_trim() gives all
+ * parked blocks back and returns the number of bytes released.  NNS_POOL_BYTES in the
+ * environment caps what the pool may hold (default 16 GiB; 0 disables pooling). */
+size_t nns_trim(void);
 
 #ifdef __cplusplus
 }

@@ -95,14 +95,11 @@ struct AccSet {
 #endif
 constexpr int kAblate = NNS_FILTER_ABLATE;
 
-constexpr int F_SB = 2;                  // 32-ref image blocks per ring slot
 constexpr int F_D = 4;                   // ring depth
-constexpr int F_BLK_BYTES = 16384;       // one image block: 32 points x (128 fp32 | 256 bf16)
-constexpr int F_SLOT_COORD = F_SB * F_BLK_BYTES;
-constexpr int F_SLOT_BYTES = F_SLOT_COORD + F_SB * 32 * 4;
+constexpr int F_SLOT_COORD = 32768;      // image bytes of one ring slot (32 fragment steps x 1 KiB)
+constexpr int F_SLOT_NORM = 1024;        // room for the slot's norms (64 or 256 floats)
+constexpr int F_SLOT_BYTES = F_SLOT_COORD + F_SLOT_NORM;
 constexpr int F_LDS_BYTES = F_D * F_SLOT_BYTES;
-constexpr int F_STEPS = 16;              // ds_read_b128 per lane per image block
-static_assert(F_SB * 32 == 64, "the norm piece is one dword per lane");
 
 // ---- operand traits ---------------------------------------------------------------
 // query blocks (of 32) per wave: their B operands stay resident in VGPRs (64 each).  More
@@ -121,7 +118,9 @@ static_assert(F_SB * 32 == 64, "the norm piece is one dword per lane");
 #define NNS_F_NW_BF16 8
 #endif
 
-struct OpF32 {   // KT = 128: float4 #b = operands of MFMA k-steps 4b .. 4b+3
+template <int SPB>
+struct OpF32T {  // fp32 operands: float4 #b = operands of MFMA k-steps 4b .. 4b+3 (8 dims per fragment)
+    static constexpr int kSPB = SPB;          // fragment steps per 32-point image block: KT = 8 * SPB
     static constexpr int kQB = NNS_F_QB_F32;
     static constexpr int kNW = NNS_F_NW_F32;
 #ifndef NNS_F_PF
@@ -137,13 +136,17 @@ struct OpF32 {   // KT = 128: float4 #b = operands of MFMA k-steps 4b .. 4b+3
         return acc;
     }
 };
+using OpF32 = OpF32T<16>;      // KT = 128
+using OpF32K32 = OpF32T<4>;    // KT = 32: the mid-range dimensionalities (k = 8 .. 32)
+
 struct OpBF16 {  // KT = 256: 16 bytes = 8 bf16 = one v_mfma_f32_32x32x16_bf16 operand
+    static constexpr int kSPB = 16;
     static constexpr int kQB = NNS_F_QB_BF16;
     static constexpr int kNW = NNS_F_NW_BF16;
 #ifndef NNS_F_PF_BF16
 #define NNS_F_PF_BF16 2
 #endif
-    static constexpr int kPrefetch = NNS_F_PF_BF16;   // one MFMA (32 cycles) per fragment and query block: deeper prefetch
+    static constexpr int kPrefetch = NNS_F_PF_BF16;   // one MFMA (32 cycles) per fragment and query block
     __device__ static __forceinline__ f32x16 mma(const float4 &a, const float4 &b, f32x16 acc)
     {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
@@ -195,22 +198,29 @@ template <class OP>
 __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a)
 {
     constexpr int F_NW = OP::kNW;
+    constexpr int SPB = OP::kSPB;                      // fragment steps per image block
+    constexpr int BPS = 32 / SPB;                      // image blocks per ring slot (2 or 8)
+    constexpr int BLK_BYTES = SPB * 1024;
+    constexpr int SLOT_REFS = 32 * BPS;
     constexpr int F_PPW = F_SLOT_COORD / 1024 / F_NW;   // 1 KiB DMA pieces per wave per slot
+    static_assert(32 % SPB == 0 && SPB >= 4, "a slot is 32 fragment steps");
+    static_assert(SLOT_REFS == 64 || SLOT_REFS == 256, "norm piece: one dword or one dwordx4 per lane");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
     constexpr int QB = OP::kQB;
+    static_assert(QB <= 2, "AccSet holds two query blocks");
     const int qblk0 = (blockIdx.x * F_NW + wave) * QB;
 
-    // ---- resident B operands: this wave's QB x 32 queries, all of K (64 VGPRs each) ------
-    float4 bq[QB][F_STEPS];
+    // ---- resident B operands: this wave's QB x 32 queries, all of K (4 VGPRs per step) -----
+    float4 bq[QB][SPB];
     TauConsts tc[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const float4 *src = a.qimg + (size_t)(qblk0 + qb) * (F_STEPS * 64) + lane;
+        const float4 *src = a.qimg + (size_t)(qblk0 + qb) * (SPB * 64) + lane;
 #pragma unroll
-        for (int b = 0; b < F_STEPS; ++b) bq[qb][b] = src[b * 64];
+        for (int b = 0; b < SPB; ++b) bq[qb][b] = src[b * 64];
         tc[qb] = tau_consts(a.kt, a.qnorm[(qblk0 + qb) * 32 + (lane & 31)],
                             __uint_as_float(a.scal->ymax2_bits), a.bf16 != 0);
     }
@@ -219,13 +229,13 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-        for (int b = 0; b < F_STEPS; ++b)
+        for (int b = 0; b < SPB; ++b)
             asm volatile("" : "+v"(bq[qb][b].x), "+v"(bq[qb][b].y), "+v"(bq[qb][b].z), "+v"(bq[qb][b].w));
         asm volatile("" : "+v"(tc[qb].c0), "+v"(tc[qb].c1), "+v"(tc[qb].x2));
     }
 
     unsigned long long st_t0 = 0, st_r0 = 0;
-    if (a.stamps) {   // diagnostic build of the launch only: in-kernel clock = d(memtime) / d(memrealtime) * 100 MHz
+    if (a.stamps) {   // diagnostic launches only: in-kernel clock = d(memtime) / d(memrealtime) * 100 MHz
         st_t0 = __builtin_amdgcn_s_memtime();
         st_r0 = __builtin_amdgcn_s_memrealtime();
     }
@@ -234,17 +244,20 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     if (ns > a.slots_per_split) ns = a.slots_per_split;
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
 
-    // DMA piece p (0 .. F_PPW: 1 KiB image pieces, then the norm piece) of slot s (relative
-    // to slot0) into ring position s % F_D
+    // DMA piece p (0 .. F_PPW-1: 1 KiB image pieces; F_PPW: the norms) of slot s (relative to
+    // slot0) into ring position s % F_D
     auto issue_piece = [&](int s, int p) __attribute__((always_inline)) {
         const size_t gslot = (size_t)(slot0 + s);
         const unsigned dst = lds_base + (s & (F_D - 1)) * F_SLOT_BYTES;
         if (p < F_PPW) {
             const int piece = wave * F_PPW + p;
             dma16(a.rimg + gslot * F_SLOT_COORD + piece * 1024 + lane * 16, dst + piece * 1024);
-        } else {
-            // the slot's 64 norms: every wave copies the same 256 B (same bytes, same words)
+        } else if constexpr (SLOT_REFS == 64) {
+            // the slot's norms: every wave copies the same bytes to the same words (keeps each
+            // wave's DMA count per slot identical)
             dma4(a.rnorm + gslot * 64 + lane, dst + F_SLOT_COORD);
+        } else {
+            dma16(a.rnorm + gslot * 256 + lane * 4, dst + F_SLOT_COORD);
         }
     };
     auto issue = [&](int s) __attribute__((always_inline)) {
@@ -267,7 +280,6 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     }
 
     // accumulators start at |y'_j|^2 of their rows: rows (r&3) + 8(r>>2) + 4h
-    static_assert(QB <= 2, "AccSet holds two query blocks");
     auto seed = [&](AccSet &acc, const char *slot, int blk) __attribute__((always_inline)) {
         const float *nrm = reinterpret_cast<const float *>(slot + F_SLOT_COORD) + blk * 32 + 4 * h;
 #pragma unroll
@@ -322,7 +334,9 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         }
     };
     auto epilogue = [&](const AccSet &acc, int blk_global) __attribute__((always_inline)) {
-        static_for<QB>([&](auto qb_c) __attribute__((always_inline)) { epilogue1(acc.template at<decltype(qb_c)::value>(), blk_global, qb_c); });
+        static_for<QB>([&](auto qb_c) __attribute__((always_inline)) {
+            epilogue1(acc.template at<decltype(qb_c)::value>(), blk_global, qb_c);
+        });
     };
     auto mma_all = [&](AccSet &acc, const float4 &frag, auto b_c) __attribute__((always_inline)) {
         constexpr int b = decltype(b_c)::value;
@@ -333,55 +347,51 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     };
 
     // ---- the software pipeline of one barrier interval -----------------------------------
-    // An interval is 32 fragment steps (2 image blocks x 16 fragments; one step = one
-    // ds_read_b128 + its MFMA(s)).  Waves 0..3 (LAG = 0) run blocks 0 and 1 of the current
-    // slot; waves 4..7 (LAG = 1) run half a block behind: the second half of the previous
-    // slot's block 1, all of block 0, the first half of block 1.  Even blocks accumulate
-    // in accA, odd blocks in accB, so a finished tile's epilogue is issued one step INTO
-    // the next tile's MFMA chain (its VALU work runs in the MFMA shadow) and the next
-    // tile's norms are read straight into the free accumulator well ahead of its start.
-    // Fragments are prefetched PF steps ahead through a register ring that is carried
-    // ACROSS the barrier: the ring is 4 slots deep and the barrier of interval s confirms
-    // slot s + 1, so the first fragments (and the seed) of interval s + 1 are already in
-    // flight when its barrier releases and the MFMA chain restarts at once.
+    // An interval is the 32 fragment steps of one ring slot (BPS image blocks x SPB fragments;
+    // one step = one ds_read_b128 + its MFMAs for the wave's query blocks).  Waves 0..3
+    // (LAG = 0) run the slot's blocks in order; waves 4..7 (LAG = 1) run HALF A BLOCK behind
+    // (they start each interval with the second half of the previous slot's last block), so
+    // one SIMD partner's tile boundary (epilogue, accumulator re-seed from the norms) falls in
+    // the middle of the other's MFMA chain.  Fragments are prefetched PF steps ahead through
+    // a register ring that is carried ACROSS the barrier: the LDS ring is 4 slots deep and the
+    // barrier of interval s confirms slot s + 1, so the first fragments of interval s + 1 are
+    // already in flight when its barrier releases and the MFMA chain restarts at once.
     constexpr int PF = OP::kPrefetch;
-    constexpr bool DB = QB == 1;   // two accumulator sets (deferred epilogue) only when they fit
     constexpr int RING = PF < 4 ? 4 : 8;
-    static_assert(PF < RING && 32 % RING == 0, "prefetch ring");
-    AccSet accA, accB;
+    constexpr int LAGOFF = SPB / 2;
+    static_assert(PF < RING && 32 % RING == 0 && PF <= LAGOFF, "prefetch ring");
+    AccSet acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accA.v0[r] = accA.v1[r] = accB.v0[r] = accB.v1[r] = __builtin_inff();
+    for (int r = 0; r < 16; ++r) acc.v0[r] = acc.v1[r] = __builtin_inff();
     float4 fr[RING];
 
     auto frag_ptr = [&](const char *slot, int blk, int f) __attribute__((always_inline)) {
-        return (reinterpret_cast<const float4 *>(slot + blk * F_BLK_BYTES) + lane) + f * 64;
+        return (reinterpret_cast<const float4 *>(slot + blk * BLK_BYTES) + lane) + f * 64;
     };
 
     // s: slot index relative to slot0; cur/prev/nxt: ring images of slots s, s-1, s+1
     auto interval = [&](auto lag_c, int s, const char *cur, const char *prev, const char *nxt) __attribute__((always_inline)) {
         constexpr int LAG = decltype(lag_c)::value;
         const bool first = s == 0;
-        const int blk0_global = (slot0 + s) * F_SB;
-        // compile-time schedule of step t (t >= 32: step t - 32 of the NEXT interval)
-        auto blk_of = [](int t) constexpr { return LAG == 0 ? t / 16 : (t < 8 ? 1 : (t < 24 ? 0 : 1)); };
-        auto frag_of = [](int t) constexpr { return LAG == 0 ? t % 16 : (t < 8 ? 8 + t : (t < 24 ? t - 8 : t - 24)); };
+        const int blk0_global = (slot0 + s) * BPS;
+        // compile-time schedule: step t works on position u = t - LAG * LAGOFF of the slot's
+        // fragment stream (u < 0: tail of the previous slot; u >= 32: head of the next one)
         auto load = [&](auto tc_) __attribute__((always_inline)) {
             constexpr int t = decltype(tc_)::value;
-            if constexpr (t < 32) {
-                const char *base = (LAG == 1 && t < 8) ? prev : cur;
-                fr[t % RING] = *frag_ptr(base, blk_of(t), frag_of(t));
-            } else {   // next interval: LAG 0 reads the confirmed slot s+1, LAG 1 finishes this slot
-                constexpr int u = t - 32;   // (in the last interval LAG 0 reads a stale ring slot: unused)
-                fr[t % RING] = *frag_ptr(LAG == 1 ? cur : nxt, LAG == 1 ? 1 : 0, LAG == 1 ? 8 + u : u);
-            }
+            constexpr int u = t - LAG * LAGOFF;
+            if constexpr (u < 0) fr[t % RING] = *frag_ptr(prev, BPS - 1, SPB + u);
+            else if constexpr (u < 32) fr[t % RING] = *frag_ptr(cur, u / SPB, u % SPB);
+            else fr[t % RING] = *frag_ptr(nxt, (u - 32) / SPB, (u - 32) % SPB);   // (last interval: stale slot, unused)
         };
         static_for<32>([&](auto tc_) __attribute__((always_inline)) {
             constexpr int t = decltype(tc_)::value;
-            constexpr int blk = blk_of(t), b = frag_of(t);
+            constexpr int u = t - LAG * LAGOFF;
+            constexpr int blk = u < 0 ? BPS - 1 : u / SPB;
+            constexpr int b = u < 0 ? SPB + u : u % SPB;
             load(std::integral_constant<int, t + PF>{});
-            // DMA two slots ahead, in the MFMA shadow (past the end: into the image's padding)
-            // one DMA piece per step, in the MFMA shadow, at different steps for the two SIMD
-            // partners (an LDS-DMA issue stalls the issuing wave for ~100 cycles)
+            // one DMA piece per step, two slots ahead, in the MFMA shadow, at different steps
+            // for the two SIMD partners (an LDS-DMA issue stalls the issuing wave ~100 cycles;
+            // past the end of the shard it reads the image's padding)
             if constexpr ((kAblate & 16) == 0) {
                 constexpr int d0 = LAG == 0 ? 2 : 16;
                 constexpr int sp = (F_PPW + 1) * 2 <= 14 ? 2 : 1;   // steps between pieces
@@ -389,31 +399,15 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                 if constexpr (t >= d0 && t < d0 + sp * (F_PPW + 1) && (t - d0) % sp == 0)
                     issue_piece(s + 2, (t - d0) / sp);
             }
-            if constexpr (DB) {
-                if constexpr (LAG == 1 && t == 0) seed(accA, cur, 0);          // used from step 8 on
-                // the other accumulator is free once its epilogue (below) has run: seed it early
-                if constexpr ((LAG == 0 && t == 4) || (LAG == 1 && t == 12)) seed(accB, cur, 1);
-                if constexpr (LAG == 0 && t == 28) seed(accA, nxt, 0);          // next interval's block 0
-            } else {
-                // single accumulator set: a tile is seeded right where it starts
-                if constexpr (b == 0) seed(accA, cur, blk);
-            }
-            // (LAG 1, very first interval: steps 0..7 chew on a not-yet-written ring slot; their
-            //  accumulator is discarded below and re-seeded at step 12)
-            if constexpr (blk == 0 || !DB) mma_all(accA, fr[t % RING], std::integral_constant<int, b>{});
-            else mma_all(accB, fr[t % RING], std::integral_constant<int, b>{});
-            // deferred epilogues: one step into the following tile
-            if constexpr (DB) {
-                if constexpr ((LAG == 0 && t == 1) || (LAG == 1 && t == 9)) {
-                    if (!first) epilogue(accB, blk0_global - 1);                 // previous slot's block 1
-                }
-                if constexpr ((LAG == 0 && t == 17) || (LAG == 1 && t == 25)) epilogue(accA, blk0_global);
-            } else if constexpr (b == F_STEPS - 1) {
-                // single accumulator set: the tile's epilogue right at its end
-                if constexpr (LAG == 1 && t < 8) {
-                    if (!first) epilogue(accA, blk0_global - 1);
+            if constexpr (b == 0) seed(acc, cur, blk);   // a tile is seeded right where it starts
+            // (LAG 1, very first interval: its first LAGOFF steps chew on a not-yet-written ring
+            //  slot; that accumulator is discarded below and re-seeded at the next tile)
+            mma_all(acc, fr[t % RING], std::integral_constant<int, b>{});
+            if constexpr (b == SPB - 1) {                // the tile's epilogue right at its end
+                if constexpr (u < 0) {
+                    if (!first) epilogue(acc, blk0_global - 1);
                 } else {
-                    epilogue(accA, blk0_global + blk);
+                    epilogue(acc, blk0_global + blk);
                 }
             }
 #ifndef NNS_F_NOSCHED
@@ -429,9 +423,6 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
 #else
     const bool lag = wave >= F_NW / 2;   // wave-uniform
 #endif
-#ifdef NNS_F_PRIO
-    if (lag) __builtin_amdgcn_s_setprio(1);
-#endif
     auto ring = [&](int s) __attribute__((always_inline)) { return smem + ((s + F_D) & (F_D - 1)) * F_SLOT_BYTES; };
     static_assert((F_D & (F_D - 1)) == 0, "ring depth must be a power of two");
 
@@ -443,11 +434,9 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // (LAG 1 reads ring slot -1 here: garbage in, discarded — see the interval)
     static_for<PF>([&](auto t) __attribute__((always_inline)) {
         constexpr int tt = decltype(t)::value;
-        fr[tt % RING] = *frag_ptr(lag ? ring(-1) : ring(0), lag ? 1 : 0, lag ? 8 + tt : tt);
+        if (lag) fr[tt % RING] = *frag_ptr(ring(-1), BPS - 1, SPB - LAGOFF + tt);
+        else fr[tt % RING] = *frag_ptr(ring(0), 0, tt);
     });
-    if constexpr (DB) {
-        if (!lag) seed(accA, ring(0), 0);
-    }
     for (int s = 0; s < ns; ++s) {
         if constexpr ((kAblate & 1) == 0) {
             // my share of slot s+1 has landed (issued an interval ago; the only DMA in flight)
@@ -458,19 +447,14 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         if (!lag) interval(I0{}, s, ring(s), ring(s - 1), ring(s + 1));
         else interval(I1{}, s, ring(s), ring(s - 1), ring(s + 1));
     }
-    {
-        const int last_blk1 = (slot0 + ns - 1) * F_SB + 1;
-        if (lag) {   // the lagging half block of the last slot; its first PF fragments are in the ring
-            const char *lastp = ring(ns - 1);
-            static_for<F_STEPS / 2>([&](auto tc_) __attribute__((always_inline)) {
-                constexpr int t = decltype(tc_)::value;
-                if constexpr (t + PF < F_STEPS / 2) fr[(t + PF) % RING] = *frag_ptr(lastp, 1, 8 + t + PF);
-                if constexpr (DB) mma_all(accB, fr[t % RING], std::integral_constant<int, 8 + t>{});
-                else mma_all(accA, fr[t % RING], std::integral_constant<int, 8 + t>{});
-            });
-        }
-        if constexpr (DB) epilogue(accB, last_blk1);
-        else if (lag) epilogue(accA, last_blk1);
+    if (lag) {   // the lagging half block of the last slot; its first PF fragments are in the ring
+        const char *lastp = ring(ns - 1);
+        static_for<LAGOFF>([&](auto tc_) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc_)::value;
+            if constexpr (t + PF < LAGOFF) fr[(t + PF) % RING] = *frag_ptr(lastp, BPS - 1, SPB - LAGOFF + t + PF);
+            mma_all(acc, fr[t % RING], std::integral_constant<int, SPB - LAGOFF + t>{});
+        });
+        epilogue(acc, (slot0 + ns) * BPS - 1);
     }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) a.counts[(lblk0 + qb) * 64 + lane] = cnt[qb];
@@ -531,7 +515,8 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g)
     if (bf16) {
         if (k <= 256) kt = 256;
     } else {
-        if (k <= 128) kt = 128;
+        if (k <= 32) kt = 32;          // OpF32K32: 4 fragment steps per block, 8 blocks per slot
+        else if (k <= 128) kt = 128;
     }
     if (!kt) {
         set_error("MFMA filter: k = %d exceeds the %s tile depth", k, bf16 ? "bf16 (256)" : "fp32 (128)");
@@ -541,7 +526,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g)
     g->kt = kt;
     const int qw = 32 * (bf16 ? OpBF16::kQB * OpBF16::kNW : OpF32::kQB * OpF32::kNW);   // queries per workgroup
     g->m_pad = divup(m, qw) * qw;
-    const int slot_pts = 32 * F_SB;
+    const int slot_pts = (kt == 32) ? 256 : 64;   // refs per ring slot (32 fragment steps)
     g->n_pad = divup(n, slot_pts) * slot_pts;
     g->total_slots = g->n_pad / slot_pts;
     g->qgroups = g->m_pad / qw;
@@ -612,7 +597,8 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
     const char *clk = getenv("NNS_FILTER_CLOCK");
     const size_t nwg = (size_t)g.qgroups * g.splits;
     if (clk && atoi(clk)) NNS_HIP(hipMalloc(&a.stamps, nwg * 4 * sizeof(unsigned long long)));
-    const int rc = g.bf16 ? launch_filter_t<OpBF16>(g, a, st) : launch_filter_t<OpF32>(g, a, st);
+    const int rc = g.bf16 ? launch_filter_t<OpBF16>(g, a, st)
+                          : (g.kt == 32 ? launch_filter_t<OpF32K32>(g, a, st) : launch_filter_t<OpF32>(g, a, st));
     if (a.stamps) {   // diagnostic: synchronous read-out, median clock over workgroups
         std::vector<unsigned long long> h(nwg * 4);
         NNS_HIP(hipStreamSynchronize(st));

@@ -136,17 +136,20 @@ int nns_index_destroy(nns_index *ix)
 {
     if (!ix) return NNS_OK;
     (void)hipSetDevice(ix->device);
-    (void)hipFree(ix->rimg);
-    (void)hipFree(ix->rnorm);
-    (void)hipFree(ix->mean);
-    (void)hipFree(ix->mean_ws);
-    (void)hipFree(ix->scal);
-    (void)hipFree(ix->qimg);
-    (void)hipFree(ix->qnorm);
-    (void)hipFree(ix->lists);
-    (void)hipFree(ix->counts);
-    (void)hipFree(ix->amb_list);
-    (void)hipFree(ix->exact_ws);
+    // workspaces go back to the pool, not to hipFree (which would wait for the device itself):
+    // make sure nothing still reads them
+    (void)hipDeviceSynchronize();
+    pool_free(ix->rimg);
+    pool_free(ix->rnorm);
+    pool_free(ix->mean);
+    pool_free(ix->mean_ws);
+    pool_free(ix->scal);
+    pool_free(ix->qimg);
+    pool_free(ix->qnorm);
+    pool_free(ix->lists);
+    pool_free(ix->counts);
+    pool_free(ix->amb_list);
+    pool_free(ix->exact_ws);
     if (ix->ev_valid)
         for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ix->ev[i]);
     delete ix;
@@ -181,7 +184,10 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
 
     const int kmax = bf16 ? 256 : 128;   // tile depth of the MFMA filter
     int path = flags & NNS_PATH_MASK;
-    if (path == NNS_PATH_AUTO) path = (k >= 32 && k <= kmax) ? NNS_PATH_MFMA : NNS_PATH_EXACT;
+    // crossover: from k = 8 the MFMA filter (KT = 32 tile) beats 3k VALU ops per pair; bf16 tiles
+    // are 256 deep, so they only pay from k = 32
+    const int kmin = bf16 ? 32 : 8;
+    if (path == NNS_PATH_AUTO) path = (k >= kmin && k <= kmax) ? NNS_PATH_MFMA : NNS_PATH_EXACT;
     if (path == NNS_PATH_MFMA && k > kmax) {
         set_error("NNS_PATH_MFMA: k = %d > %d is not tiled yet (use NNS_PATH_AUTO/EXACT)", k, kmax);
         delete ix;
@@ -206,12 +212,12 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
             const FilterGeom &g = ix->geom;
             size_t ws = 0;
             prep_workspace_bytes(g.kt, &ws);
-            // + 128 rows: the filter's ring DMA runs two 64-ref slots past the last one
-            if (hipMalloc(&ix->rimg, (size_t)(g.n_pad + 128) * (F_IMG_ROW_BYTES)) != hipSuccess ||
-                hipMalloc(&ix->rnorm, (size_t)(g.n_pad + 128) * sizeof(float)) != hipSuccess ||
-                hipMalloc(&ix->mean, (size_t)g.kt * sizeof(float)) != hipSuccess ||
-                hipMalloc(&ix->mean_ws, ws) != hipSuccess ||
-                hipMalloc(&ix->scal, sizeof(DevScalars)) != hipSuccess) {
+            // + 512 rows: the filter's ring DMA runs two slots (64 or 256 refs each) past the last one
+            if (pool_alloc(&ix->rimg, (size_t)(g.n_pad + 512) * (F_IMG_ROW_BYTES)) != hipSuccess ||
+                pool_alloc(&ix->rnorm, (size_t)(g.n_pad + 512) * sizeof(float)) != hipSuccess ||
+                pool_alloc(&ix->mean, (size_t)g.kt * sizeof(float)) != hipSuccess ||
+                pool_alloc(&ix->mean_ws, ws) != hipSuccess ||
+                pool_alloc(&ix->scal, sizeof(DevScalars)) != hipSuccess) {
                 set_error("nns_index_create: device allocation failed (n_pad=%d kt=%d)", g.n_pad, g.kt);
                 rc = NNS_ERR_NOMEM;
                 break;
@@ -270,17 +276,17 @@ static int ensure_query_ws(nns_index *ix, int m)
     ix->geom = gq;   // same kt / n_pad / total_slots; m-dependent grid now filled in
     (void)g;
     if (gq.m_pad > ix->m_cap) {
-        (void)hipFree(ix->qimg);
-        (void)hipFree(ix->qnorm);
-        (void)hipFree(ix->amb_list);
-    (void)hipFree(ix->exact_ws);
+        if (ix->qimg) (void)hipDeviceSynchronize();   // an earlier search may still read them
+        pool_free(ix->qimg);
+        pool_free(ix->qnorm);
+        pool_free(ix->amb_list);
         ix->qimg = nullptr;
         ix->qnorm = nullptr;
         ix->amb_list = nullptr;
         ix->m_cap = 0;
-        if (hipMalloc(&ix->qimg, (size_t)gq.m_pad * (F_IMG_ROW_BYTES)) != hipSuccess ||
-            hipMalloc(&ix->qnorm, (size_t)gq.m_pad * sizeof(float)) != hipSuccess ||
-            hipMalloc(&ix->amb_list, (size_t)gq.m_pad * sizeof(int)) != hipSuccess) {
+        if (pool_alloc(&ix->qimg, (size_t)gq.m_pad * (F_IMG_ROW_BYTES)) != hipSuccess ||
+            pool_alloc(&ix->qnorm, (size_t)gq.m_pad * sizeof(float)) != hipSuccess ||
+            pool_alloc(&ix->amb_list, (size_t)gq.m_pad * sizeof(int)) != hipSuccess) {
             set_error("query workspace allocation failed (m_pad=%d)", gq.m_pad);
             return NNS_ERR_NOMEM;
         }
@@ -288,13 +294,14 @@ static int ensure_query_ws(nns_index *ix, int m)
     }
     const size_t need = (size_t)gq.splits * gq.m_pad * 2;   // lane-lists
     if (need > ix->lists_cap) {
-        (void)hipFree(ix->lists);
-        (void)hipFree(ix->counts);
+        if (ix->lists) (void)hipDeviceSynchronize();
+        pool_free(ix->lists);
+        pool_free(ix->counts);
         ix->lists = nullptr;
         ix->counts = nullptr;
         ix->lists_cap = 0;
-        if (hipMalloc(&ix->lists, need * kCandCap * sizeof(CandEntry)) != hipSuccess ||
-            hipMalloc(&ix->counts, need * sizeof(int)) != hipSuccess) {
+        if (pool_alloc(&ix->lists, need * kCandCap * sizeof(CandEntry)) != hipSuccess ||
+            pool_alloc(&ix->counts, need * sizeof(int)) != hipSuccess) {
             set_error("candidate list allocation failed (%zu lists)", need);
             return NNS_ERR_NOMEM;
         }
@@ -330,10 +337,11 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
         {
             const size_t need = exact_workspace_keys(ix->k, m, ix->n);
             if (need > ix->exact_ws_keys) {
-                (void)hipFree(ix->exact_ws);
+                if (ix->exact_ws) (void)hipDeviceSynchronize();
+                pool_free(ix->exact_ws);
                 ix->exact_ws = nullptr;
                 ix->exact_ws_keys = 0;
-                if (hipMalloc(&ix->exact_ws, need * sizeof(nns_key)) == hipSuccess) ix->exact_ws_keys = need;
+                if (pool_alloc(&ix->exact_ws, need * sizeof(nns_key)) == hipSuccess) ix->exact_ws_keys = need;
                 else (void)hipGetLastError();   // no workspace: K1a falls back to atomics
             }
             NNS_TRY(launch_exact_search(ix->k, m, ix->n, (const float *)q_dev, (const float *)ix->r_dev, ix->base,
@@ -449,7 +457,7 @@ int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const fl
     NNS_TRY(ensure_device_ok(0));
     float *d = nullptr;
     const size_t na = (size_t)32 * kt, total = 2 * na + 32 + 1024;
-    NNS_HIP(hipMalloc(&d, total * sizeof(float)));
+    NNS_HIP(pool_alloc(&d, total * sizeof(float)));
     int rc = NNS_OK;
     if (hipMemcpy(d, a, na * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d + na, b, na * 4, hipMemcpyHostToDevice) != hipSuccess ||
@@ -459,7 +467,7 @@ int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const fl
     if (rc == NNS_OK && hipMemcpy(out, d + 2 * na + 32, 1024 * 4, hipMemcpyDeviceToHost) != hipSuccess)
         rc = NNS_ERR_HIP;
     if (rc == NNS_ERR_HIP) set_error("nns_selftest_mfma: %s", hipGetErrorString(hipGetLastError()));
-    (void)hipFree(d);
+    pool_free(d);
     return rc;
 }
 
@@ -489,11 +497,11 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
     nns_index *ix = nullptr;
     do {
         const size_t qb = (size_t)m * k * esz, rb = (size_t)n * k * esz;
-        if (hipMalloc(&q_d, qb) != hipSuccess || hipMalloc(&r_d, rb) != hipSuccess ||
-            hipMalloc(&keys, (size_t)m * sizeof(nns_key)) != hipSuccess ||
-            hipMalloc(&keys_tmp, (size_t)m * sizeof(nns_key)) != hipSuccess ||
-            hipMalloc(&idx_d, (size_t)m * sizeof(int)) != hipSuccess ||
-            hipMalloc(&dist_d, (size_t)m * sizeof(float)) != hipSuccess) {
+        if (pool_alloc(&q_d, qb) != hipSuccess || pool_alloc(&r_d, rb) != hipSuccess ||
+            pool_alloc(&keys, (size_t)m * sizeof(nns_key)) != hipSuccess ||
+            pool_alloc(&keys_tmp, (size_t)m * sizeof(nns_key)) != hipSuccess ||
+            pool_alloc(&idx_d, (size_t)m * sizeof(int)) != hipSuccess ||
+            pool_alloc(&dist_d, (size_t)m * sizeof(float)) != hipSuccess) {
             set_error("nns_search_f32: device allocation failed");
             rc = NNS_ERR_NOMEM;
             break;
@@ -532,12 +540,12 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             rc = NNS_ERR_HIP;
         }
     } while (0);
-    (void)hipFree(q_d);
-    (void)hipFree(r_d);
-    (void)hipFree(keys);
-    (void)hipFree(keys_tmp);
-    (void)hipFree(idx_d);
-    (void)hipFree(dist_d);
+    pool_free(q_d);
+    pool_free(r_d);
+    pool_free(keys);
+    pool_free(keys_tmp);
+    pool_free(idx_d);
+    pool_free(dist_d);
     return rc;
 }
 

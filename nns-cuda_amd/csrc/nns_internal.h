@@ -29,6 +29,12 @@ void set_error(const char *fmt, ...);
         if (nns_s_ != NNS_OK) return nns_s_;                                   \
     } while (0)
 
+// ---- pooled device workspaces (dev_pool.hip) -----------------------------------
+hipError_t pool_alloc(void **out, size_t bytes);
+template <class T> static inline hipError_t pool_alloc(T **out, size_t bytes) { return pool_alloc((void **)out, bytes); }
+void pool_free(void *ptr);     // caller has synchronised the work that used ptr
+size_t pool_trim();            // give every parked block back to the runtime
+
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t divup64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -79,8 +79,8 @@ static void run_shard(ShardJob *job, int k, int m, const float *q, const float *
     };
     if (hipSetDevice(job->device) != hipSuccess) return fail(NNS_ERR_HIP, "hipSetDevice");
     const size_t qb = (size_t)m * k * sizeof(float), rb = (size_t)job->cnt * k * sizeof(float);
-    if (hipMalloc(&job->q_d, qb) != hipSuccess || hipMalloc(&job->r_d, rb) != hipSuccess ||
-        hipMalloc(&job->keys, (size_t)m * sizeof(nns_key)) != hipSuccess)
+    if (pool_alloc(&job->q_d, qb) != hipSuccess || pool_alloc(&job->r_d, rb) != hipSuccess ||
+        pool_alloc(&job->keys, (size_t)m * sizeof(nns_key)) != hipSuccess)
         return fail(NNS_ERR_NOMEM, "device allocation");
     if (hipMemcpy(job->q_d, q, qb, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(job->r_d, r + (size_t)job->beg * k, rb, hipMemcpyHostToDevice) != hipSuccess)
@@ -193,23 +193,23 @@ extern "C" int nns_search_f32_multi(int k, int m, int n, const float *s_points, 
         // unpack on device 0 (every device holds the reduced keys after the all-reduce)
         int *idx_d = nullptr;
         float *dist_d = nullptr;
-        if (rc == NNS_OK && (hipMalloc(&idx_d, (size_t)m * sizeof(int)) != hipSuccess ||
-                             hipMalloc(&dist_d, (size_t)m * sizeof(float)) != hipSuccess))
+        if (rc == NNS_OK && (pool_alloc(&idx_d, (size_t)m * sizeof(int)) != hipSuccess ||
+                             pool_alloc(&dist_d, (size_t)m * sizeof(float)) != hipSuccess))
             rc = NNS_ERR_NOMEM;
         if (rc == NNS_OK) rc = nns_keys_unpack(jobs[0].keys, m, idx_d, dist_d, nullptr);
         if (rc == NNS_OK &&
             (hipMemcpy(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
              (dist_out && hipMemcpy(dist_out, dist_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)))
             rc = NNS_ERR_HIP;
-        (void)hipFree(idx_d);
-        (void)hipFree(dist_d);
+        pool_free(idx_d);
+        pool_free(dist_d);
         if (rc == NNS_ERR_HIP) set_error("nns_search_f32_multi: merge/unpack failed: %s", hipGetErrorString(hipGetLastError()));
     }
     for (int g = 0; g < G; ++g) {
         (void)hipSetDevice(jobs[g].device);
-        (void)hipFree(jobs[g].q_d);
-        (void)hipFree(jobs[g].r_d);
-        (void)hipFree(jobs[g].keys);
+        pool_free(jobs[g].q_d);
+        pool_free(jobs[g].r_d);
+        pool_free(jobs[g].keys);
     }
     (void)hipSetDevice(0);
     return rc;

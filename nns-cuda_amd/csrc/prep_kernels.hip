@@ -160,12 +160,19 @@ __global__ __launch_bounds__(256) void image_kernel(int k, int npts, const float
 
     // load + centre: the 32 rows are one contiguous span of 32*k floats
     unsigned mx = 0;
-    if (k == KT && p0 + 32 <= npts && (((uintptr_t)pts) & 15) == 0) {
-        // full block of full-depth rows: 16-byte loads, consecutive lanes -> consecutive bytes
-        const float4 *src = reinterpret_cast<const float4 *>(pts + (size_t)p0 * KT);
+    if ((k & 3) == 0 && k <= KT && p0 + 32 <= npts && (((uintptr_t)pts) & 15) == 0) {
+        // full block of rows: 16-byte loads, consecutive lanes -> consecutive bytes (the 32 rows
+        // are one contiguous span of 32 * k floats); dims k .. KT-1 are zero padding
+        const int k4 = k >> 2;
+        const float4 *src = reinterpret_cast<const float4 *>(pts + (size_t)p0 * k);
         const float4 *mean4 = reinterpret_cast<const float4 *>(mean);
-        for (int e = tid; e < 32 * (KT / 4); e += 256) {
-            const int i = e / (KT / 4), t4 = e - i * (KT / 4);
+        if (k < KT)
+            for (int e = tid; e < 32 * (KT / 4); e += 256) {
+                const int i = e / (KT / 4), t4 = e - i * (KT / 4);
+                if (t4 >= k4) *reinterpret_cast<float4 *>(&tile[i * LD + 4 * t4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        for (int e = tid; e < 32 * k4; e += 256) {
+            const int i = e / k4, t4 = e - i * k4;
             const float4 v = src[e];
             const float4 mc = mean4[t4];
             const unsigned b0 = __float_as_uint(v.x) & 0x7FFFFFFFu, b1 = __float_as_uint(v.y) & 0x7FFFFFFFu;
@@ -251,8 +258,8 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, c
 {
     const int blocks = npts_pad / 32;
     switch (kt) {
-    case 64:
-        hipLaunchKernelGGL(image_kernel<64>, dim3(blocks), dim3(256), 0, st, k, npts, pts, mean,
+    case 32:
+        hipLaunchKernelGGL(image_kernel<32>, dim3(blocks), dim3(256), 0, st, k, npts, pts, mean,
                            scale, pad_norm, img, norms, max_norm_bits, maxabs_bits);
         break;
     case 128:

@@ -38,6 +38,7 @@ ABI_SYMBOLS = (
     "nns_keys_unpack", "nns_fill_uniform", "nns_device_count", "nns_strerror",
     "nns_last_error", "nns_version", "nns_selftest_mfma",
     "nns_index_create_bf16", "nns_index_search_bf16", "nns_search_bf16_ex", "nns_search_f32_multi",
+    "nns_trim",
 )
 
 
@@ -99,8 +100,10 @@ def _load() -> ctypes.CDLL:
     lib.nns_last_error.restype = ctypes.c_char_p
     lib.nns_version.argtypes = []
     for name in ABI_SYMBOLS:
-        if name not in ("nns_strerror", "nns_last_error"):
+        if name not in ("nns_strerror", "nns_last_error", "nns_trim"):
             getattr(lib, name).restype = c_int
+    lib.nns_trim.argtypes = []
+    lib.nns_trim.restype = ctypes.c_size_t
     return lib
 
 
@@ -297,6 +300,11 @@ class Index:
             self.close()
         except Exception:
             pass
+
+
+def trim() -> int:
+    """nns_trim: return the pooled device workspaces to the runtime; bytes released."""
+    return int(lib.nns_trim())
 
 
 def keys_min(inout, other, stream=None) -> None:
