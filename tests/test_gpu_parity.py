@@ -472,3 +472,56 @@ def test_awkward_query_counts_balance(pkg, orc):
     for m in (513, 1537, 5000):
         q = rng.random((m, 128), dtype=np.float32)
         _check(pkg, orc, q, r, paths=("mfma",), shards=(1,))
+
+
+@pytest.mark.parametrize("shape", [(1000, 5000, 16), (300, 70001, 8), (2049, 777, 31), (65, 300000, 32),
+                                   (700, 20001, 12), (4096, 4096, 20)])
+def test_filter_k32_tile_shapes(pkg, orc, shape):
+    """8 <= k <= 32 runs the 32-deep fp32 MFMA tile (8 image blocks per ring slot): ragged m / n / k
+    vs the oracle, forced and under AUTO, whole and sharded."""
+    m, n, k = shape
+    rng = np.random.default_rng(500 + k)
+    q = rng.random((m, k), dtype=np.float32)
+    r = rng.random((n, k), dtype=np.float32)
+    _check(pkg, orc, q, r, paths=("mfma", "auto"), shards=(1, 3))
+    ix = pkg.Index(torch.from_numpy(r).cuda())
+    ix.search(torch.from_numpy(q).cuda())
+    st = ix.stats()
+    assert st["path"] == 2 and st["k_tile"] == 32, st
+    ix.close()
+
+
+def test_k32_tile_duplicates_and_specials(pkg, orc):
+    """Low-dimensional data collides far more often: exact duplicate refs (lowest index wins),
+    1-ulp twins, and NaN / INF refs that must never be selected — through the 32-deep tile."""
+    rng = np.random.default_rng(61)
+    k = 16
+    base = rng.random((5000, k), dtype=np.float32)
+    twins = base[:500].copy()
+    twins[:, 3] = np.nextafter(twins[:, 3], np.float32(2.0))
+    r = np.concatenate([base, base[:800], twins])
+    q = np.concatenate([base[:300], base[:200] + rng.normal(0, 1e-5, (200, k)).astype(np.float32)])
+    _check(pkg, orc, q, r, paths=("mfma", "auto"), shards=(1, 2))
+    r2 = r.copy()
+    r2[17, 2] = np.nan
+    r2[4000, 0] = np.inf
+    _check(pkg, orc, q, r2, paths=("mfma", "auto"), shards=(1, 2))
+
+
+def test_workspace_pool_reuse_and_trim(pkg, orc):
+    """Whole-call searches park their device workspaces in the pool (dev_pool.hip): repeated and
+    interleaved calls of different shapes give the same answers on recycled (dirty) memory, and
+    nns_trim() hands the parked bytes back."""
+    rng = np.random.default_rng(62)
+    shapes = [(300, 9000, 128), (1000, 5000, 16), (64, 100000, 3), (300, 9000, 128), (129, 7000, 64)]
+    data = [(rng.random((m, k), dtype=np.float32), rng.random((n, k), dtype=np.float32)) for m, n, k in shapes]
+    want = [orc.v0_search(q, r)[0] for q, r in data]
+    # each round recycles blocks the previous shapes left dirty (tile images, candidate lists)
+    for rep in range(3):
+        for (q, r), w in zip(data, want):
+            assert np.array_equal(pkg.search(q, r), w)
+    released = pkg.trim()
+    assert released > 0
+    assert pkg.trim() == 0
+    for (q, r), w in zip(data, want):
+        assert np.array_equal(pkg.search(q, r), w)
