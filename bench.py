@@ -31,6 +31,9 @@ import os
 import sys
 import time
 
+# the host driver only supports dmabuf IPC: RCCL across processes needs this (set before HIP starts)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 

@@ -183,7 +183,8 @@ int nns_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset,
  * b[32][kt], c0[32], out[32][32] are HOST fp32 buffers; out[i][j] = the MFMA
  * accumulation of sum_t a[i][t] * b[j][t] seeded with c0[i].  bf16 = 0:
  * v_mfma_f32_32x32x2_f32 (compared by the tests with a host fmaf() chain);
- * bf16 = 1: v_mfma_f32_32x32x16_bf16 on the values cast to bf16 (compared with
+ * bf16 = 1: v_mfma_f32_32x32x16_bf16, bf16 = 2: four 16x16 tiles of v_mfma_f32_16x16x32_bf16
+ * (the bf16 filter's shape and lane mapping), on the values cast to bf16 (compared with
  * fp64).  These are the error models behind the filter's proof margin tau. */
 int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const float *c0,
                       float *out);

@@ -88,6 +88,33 @@ struct AccSet {
     }
 };
 
+// The same 32 registers as eight 16x16 tiles [ref tile rt][query tile qt] (OpBF16)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct AccSet16 {
+    f32x4 t00, t01, t02, t03, t10, t11, t12, t13;
+    template <int RT, int QT>
+    __device__ __forceinline__ f32x4 &at()
+    {
+        static_assert(RT >= 0 && RT < 2 && QT >= 0 && QT < 4, "2 ref tiles x 4 query tiles");
+        if constexpr (RT == 0) {
+            if constexpr (QT == 0) return t00;
+            else if constexpr (QT == 1) return t01;
+            else if constexpr (QT == 2) return t02;
+            else return t03;
+        } else {
+            if constexpr (QT == 0) return t10;
+            else if constexpr (QT == 1) return t11;
+            else if constexpr (QT == 2) return t12;
+            else return t13;
+        }
+    }
+    template <int RT, int QT>
+    __device__ __forceinline__ const f32x4 &at() const
+    {
+        return const_cast<AccSet16 *>(this)->template at<RT, QT>();
+    }
+};
+
 // Timing diagnostics only (results are wrong): build with -DNNS_FILTER_ABLATE=<bits>
 //   1 no ring sync (wait + barrier), 2 no epilogue, 16 no DMA issue.  0 in the product.
 #ifndef NNS_FILTER_ABLATE
@@ -121,6 +148,9 @@ constexpr int F_LDS_BYTES = F_D * F_SLOT_BYTES;
 template <int SPB>
 struct OpF32T {  // fp32 operands: float4 #b = operands of MFMA k-steps 4b .. 4b+3 (8 dims per fragment)
     static constexpr int kSPB = SPB;          // fragment steps per 32-point image block: KT = 8 * SPB
+    static constexpr bool kTile16 = false;    // 32x32 MFMA tiles: a lane owns one query per query block
+    static constexpr bool kLag = true;        // SIMD partners half a block out of phase (+1.3 % on C3)
+    using Acc = AccSet;
     static constexpr int kQB = NNS_F_QB_F32;
     static constexpr int kNW = NNS_F_NW_F32;
 #ifndef NNS_F_PF
@@ -139,13 +169,66 @@ struct OpF32T {  // fp32 operands: float4 #b = operands of MFMA k-steps 4b .. 4b
 using OpF32 = OpF32T<16>;      // KT = 128
 using OpF32K32 = OpF32T<4>;    // KT = 32: the mid-range dimensionalities (k = 8 .. 32)
 
-struct OpBF16 {  // KT = 256: 16 bytes = 8 bf16 = one v_mfma_f32_32x32x16_bf16 operand
+// bf16, KT = 256, 16 fragment steps per 32-ref block either way; two MFMA shapes:
+//
+// OpBF16 (the product): v_mfma_f32_16x16x32_bf16.  Same flops per cycle as the 32x32x16 form,
+// but the chip holds a ~14 % higher clock on it under this loop's load (measured here on C5:
+// in-kernel clock 2.05 vs 1.80 GHz, filter 70 vs 80 ms in the bare loop; MI355X guide, 'DVFS
+// give-back' item 7).  A step = one 1 KiB fragment (16 refs x 32 dims) x the wave's FOUR
+// 16-query tiles; step b = 2 * ks + rt walks the 8 k-steps of the two 16-ref tiles alternately.
+// C layout: lane l holds query column l & 15 and ref rows 4 * (l >> 4) .. + 3 of each tile, so a
+// lane carries four queries (one per query tile) x 8 refs per block, and a query's refs are
+// spread over the four lanes l & 15 + 16 g — four lane-private candidate lists per query.
+struct OpBF16 {
     static constexpr int kSPB = 16;
-    static constexpr int kQB = NNS_F_QB_BF16;
+    static constexpr bool kTile16 = true;
+    static constexpr bool kLag = false;       // measured on C5: lock-step partners 80.1 ms, lagged 83.3
+    using Acc = AccSet16;
+    static constexpr int kQB = 2;             // 64 queries per wave = 4 query tiles
     static constexpr int kNW = NNS_F_NW_BF16;
 #ifndef NNS_F_PF_BF16
 #define NNS_F_PF_BF16 2
 #endif
+    static constexpr int kPrefetch = NNS_F_PF_BF16;
+    // Inline asm, accumulating IN PLACE: through the builtin hipcc picks the three-address form
+    // and rotates the eight 4-register accumulators through extra tuples (52-72 registers live
+    // instead of 32), which spills the resident query operands.  The compiler does not see MFMA
+    // hazards of an asm statement; the kernel keeps them by construction: an accumulator is
+    // re-used as srcC only 8 MFMAs later, and VALU reads of it (the epilogue) wait behind an
+    // explicit s_nop (mma16_fence).
+    __device__ static __forceinline__ void mma16(const float4 &a, const float4 &b, f32x4 &acc)
+    {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                     : "+v"(acc)
+                     : "v"(__builtin_bit_cast(f32x4, a)), "v"(__builtin_bit_cast(f32x4, b)));
+    }
+    // first MFMA of a tile: srcC = the refs' norms (three-address form, dst must not overlap srcC)
+    __device__ static __forceinline__ void mma16_seed(const float4 &a, const float4 &b, f32x4 &acc, const f32x4 &c)
+    {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
+                     : "=&v"(acc)
+                     : "v"(__builtin_bit_cast(f32x4, a)), "v"(__builtin_bit_cast(f32x4, b)), "v"(c));
+    }
+    // Before VALU touches just-written accumulators (passes + 3 wait states; 13 covers 8 passes).
+    // The accumulators are in/out operands so that every later read of them is ordered behind
+    // the wait — to the compiler an asm MFMA's result is ready at once, and it would otherwise
+    // hoist the epilogue's v_min3 right behind the MFMAs (stale reads: seen as wrong indices).
+    __device__ static __forceinline__ void mma16_fence(AccSet16 &c)
+    {
+        asm volatile("s_nop 7\n\ts_nop 4"
+                     : "+v"(c.t00), "+v"(c.t01), "+v"(c.t02), "+v"(c.t03), "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13));
+    }
+};
+
+// OpBF16T32: v_mfma_f32_32x32x16_bf16 (the first version; kept for A/B builds with
+// -DNNS_BF16_TILE32): 16 bytes = 8 bf16 = one operand, lane = query, 16 refs per lane.
+struct OpBF16T32 {
+    static constexpr int kSPB = 16;
+    static constexpr bool kTile16 = false;
+    static constexpr bool kLag = true;
+    using Acc = AccSet;
+    static constexpr int kQB = NNS_F_QB_BF16;
+    static constexpr int kNW = NNS_F_NW_BF16;
     static constexpr int kPrefetch = NNS_F_PF_BF16;   // one MFMA (32 cycles) per fragment and query block
     __device__ static __forceinline__ f32x16 mma(const float4 &a, const float4 &b, f32x16 acc)
     {
@@ -153,6 +236,11 @@ struct OpBF16 {  // KT = 256: 16 bytes = 8 bf16 = one v_mfma_f32_32x32x16_bf16 o
                                                        __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
 };
+#if NNS_BF16_TILE16
+using OpBF16Active = OpBF16;
+#else
+using OpBF16Active = OpBF16T32;
+#endif
 
 // LDS-DMA (global_load_lds_*): 64 lanes x {16, 4} bytes from per-lane global addresses to
 // LDS at M0 + lane * size, no VGPR destination.  Inline asm on purpose: through the
@@ -210,28 +298,50 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
     constexpr int QB = OP::kQB;
-    static_assert(QB <= 2, "AccSet holds two query blocks");
+    static_assert(QB <= 2, "the accumulator sets hold two query blocks");
     const int qblk0 = (blockIdx.x * F_NW + wave) * QB;
+    // Lane STATES: the running minimum / threshold / candidate list a lane keeps per query it
+    // carries.  32x32 tiles: one query per query block (state = block, 16 scores per ref block);
+    // 16x16 tiles: one query per 16-query tile (state = tile, 8 scores per ref block).
+    constexpr bool T16 = OP::kTile16;
+    constexpr int NS = T16 ? 2 * QB : QB;
+    constexpr int QPS = T16 ? 16 : 32;          // queries per state
+    constexpr int NBQ = T16 ? SPB / 2 : SPB;    // resident operand fragments per state
 
-    // ---- resident B operands: this wave's QB x 32 queries, all of K (4 VGPRs per step) -----
-    float4 bq[QB][SPB];
-    TauConsts tc[QB];
+    // ---- resident B operands: this wave's QB x 32 queries, all of K (128 VGPRs at QB = 2) ----
+    float4 bq[NS][NBQ];
+    TauConsts tc[NS];
+    {
+        const float4 *src = a.qimg + (size_t)qblk0 * (SPB * 64) + lane;
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const float4 *src = a.qimg + (size_t)(qblk0 + qb) * (SPB * 64) + lane;
+        for (int st = 0; st < NS; ++st) {
 #pragma unroll
-        for (int b = 0; b < SPB; ++b) bq[qb][b] = src[b * 64];
-        tc[qb] = tau_consts(a.kt, a.qnorm[(qblk0 + qb) * 32 + (lane & 31)],
-                            __uint_as_float(a.scal->ymax2_bits), a.bf16 != 0);
+            for (int b = 0; b < NBQ; ++b) bq[st][b] = src[(st * NBQ + b) * 64];
+            tc[st] = tau_consts(a.kt, a.qnorm[qblk0 * 32 + st * QPS + (lane & (QPS - 1))],
+                                __uint_as_float(a.scal->ymax2_bits), a.bf16 != 0);
+        }
     }
     // Pin the loads here: hipcc must wait for them BEFORE the ring starts, not with a
     // vmcnt(0) at their first use inside the loop (it cannot see the asm DMAs).
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
+    for (int st = 0; st < NS; ++st) {
 #pragma unroll
-        for (int b = 0; b < SPB; ++b)
-            asm volatile("" : "+v"(bq[qb][b].x), "+v"(bq[qb][b].y), "+v"(bq[qb][b].z), "+v"(bq[qb][b].w));
-        asm volatile("" : "+v"(tc[qb].c0), "+v"(tc[qb].c1), "+v"(tc[qb].x2));
+        for (int b = 0; b < NBQ; ++b)
+            asm volatile("" : "+v"(bq[st][b].x), "+v"(bq[st][b].y), "+v"(bq[st][b].z), "+v"(bq[st][b].w));
+        asm volatile("" : "+v"(tc[st].c0), "+v"(tc[st].c1), "+v"(tc[st].x2));
+    }
+    // 16x16 tiles carry four states per lane: their tau constants live in LDS behind the ring
+    // (2 KiB per wave, read only on the slow path) instead of 12 more registers; c1 depends on the
+    // tile depth alone and is wave-uniform
+    float *tcl = reinterpret_cast<float *>(smem + F_LDS_BYTES) + wave * 512 + lane;
+    float c1u = 0.0f;
+    if constexpr (T16) {
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            tcl[(2 * st) * 64] = tc[st].c0;
+            tcl[(2 * st + 1) * 64] = tc[st].x2;
+        }
+        c1u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tc[0].c1)));
     }
 
     unsigned long long st_t0 = 0, st_r0 = 0;
@@ -266,21 +376,39 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     };
 
     // ---- per-lane record state ---------------------------------------------------------
-    float m1[QB], thr[QB];
-    int cnt[QB];
-    // candidate lists are stored [split][query block][entry][lane] so that both the
-    // appends of a wave and K5's per-query reads touch consecutive 8-byte words
-    const size_t lblk0 = (size_t)blockIdx.y * (a.m_pad / 32) + qblk0;
-    CandEntry *list[QB];
+    float m1[NS], thr[NS];
+    int cnt[NS];
+    // candidate lists are stored [split][state unit][entry][lane] (unit = the 64 lanes' lists of
+    // one query block / query tile) so that both the appends of a wave and K5's per-query reads
+    // touch consecutive 8-byte words
+    const size_t lblk0 = (size_t)blockIdx.y * (a.m_pad / QPS) + (size_t)qblk0 * (32 / QPS);
+    CandEntry *list[NS];
+    CandEntry *const list0 = a.lists + lblk0 * (kCandCap * 64) + lane;
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        m1[qb] = thr[qb] = __builtin_inff();
-        cnt[qb] = 0;
-        list[qb] = a.lists + (lblk0 + qb) * (kCandCap * 64) + lane;
+    for (int st = 0; st < NS; ++st) {
+        m1[st] = thr[st] = __builtin_inff();
+        cnt[st] = 0;
+        list[st] = list0 + st * (kCandCap * 64);
     }
+    // (16x16 tiles: one base pointer + compile-time offsets, no per-state pointer registers)
+    auto list_of = [&](auto st_c) __attribute__((always_inline)) -> CandEntry * {
+        constexpr int st = decltype(st_c)::value;
+        if constexpr (T16) return list0 + st * (kCandCap * 64);
+        else return list[st];
+    };
 
+    f32x4 nseed0 = {0.0f, 0.0f, 0.0f, 0.0f}, nseed1 = nseed0;   // 16x16 tiles: the two ref tiles' norms
     // accumulators start at |y'_j|^2 of their rows: rows (r&3) + 8(r>>2) + 4h
-    auto seed = [&](AccSet &acc, const char *slot, int blk) __attribute__((always_inline)) {
+    auto seed = [&](typename OP::Acc &acc, const char *slot, int blk) __attribute__((always_inline)) {
+        if constexpr (T16) {
+            // rows 16 rt + 4 (lane >> 4) + i of every query tile
+            const float *nrm = reinterpret_cast<const float *>(slot + F_SLOT_COORD) + blk * 32 + 4 * (lane >> 4);
+            // (loaded here, consumed as srcC by the tile's first MFMAs: no register copies)
+            const float4 n0 = *reinterpret_cast<const float4 *>(nrm), n1 = *reinterpret_cast<const float4 *>(nrm + 16);
+            nseed0 = f32x4{n0.x, n0.y, n0.z, n0.w};
+            nseed1 = f32x4{n1.x, n1.y, n1.z, n1.w};
+            return;
+        } else {
         const float *nrm = reinterpret_cast<const float *>(slot + F_SLOT_COORD) + blk * 32 + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -294,56 +422,129 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                 acc.template at<qb>()[4 * g + 3] = nv.w;
             });
         }
-    };
-    // record collection over the 16 finished scores of one tile of query block qb
-    auto epilogue1 = [&](const f32x16 &acc, int blk_global, auto qb_c) __attribute__((always_inline)) {
-        constexpr int qb = decltype(qb_c)::value;
-        if constexpr ((kAblate & 2) != 0) {
-            asm volatile("" ::"v"(acc));
-            return;
         }
-        const float t0 = fminf(fminf(acc[0], acc[1]), acc[2]);
-        const float t1 = fminf(fminf(acc[3], acc[4]), acc[5]);
-        const float t2 = fminf(fminf(acc[6], acc[7]), acc[8]);
-        const float t3 = fminf(fminf(acc[9], acc[10]), acc[11]);
-        const float t4 = fminf(fminf(acc[12], acc[13]), acc[14]);
-        const float tm = fminf(fminf(fminf(t0, t1), acc[15]), fminf(fminf(t2, t3), t4));
-        if (__builtin_amdgcn_ballot_w64(tm <= thr[qb]) != 0ull) {   // rare: ~ln(n) tiles per lane
-            const int jbase = blk_global * 32 + 4 * h;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float x = acc[r];
-                if (x <= thr[qb] && x < __builtin_inff()) {
-                    const int pos = cnt[qb] & (kCandCap - 1);
-                    if ((cnt[qb] & kCandCountMask) >= kCandCap) {
-                        // ring wrap: the slot's old entry may only be dropped if it is above the
-                        // current threshold (then it can never be within tau of the final minimum)
-                        if (list[qb][pos * 64].s <= thr[qb]) cnt[qb] |= kCandOverflow;
-                    }
-                    CandEntry e;
-                    e.s = x;
-                    e.j = jbase + (r & 3) + 8 * (r >> 2);
-                    list[qb][pos * 64] = e;
-                    ++cnt[qb];
-                    if (x < m1[qb]) {
-                        m1[qb] = x;
-                        thr[qb] = x + tau_of(tc[qb], x) * 1.002f;   // a hair wider than K5's own tau
-                    }
-                }
+    };
+    // one finished score x of ref j (slow path): append to the state's candidate ring, tighten
+    auto record = [&](auto st_c, float x, int j) __attribute__((always_inline)) {
+        constexpr int st = decltype(st_c)::value;
+        if (x <= thr[st] && x < __builtin_inff()) {
+            const int pos = cnt[st] & (kCandCap - 1);
+            CandEntry *const lst = list_of(st_c);
+            if ((cnt[st] & kCandCountMask) >= kCandCap) {
+                // ring wrap: the slot's old entry may only be dropped if it is above the
+                // current threshold (then it can never be within tau of the final minimum)
+                if (lst[pos * 64].s <= thr[st]) cnt[st] |= kCandOverflow;
+            }
+            CandEntry e;
+            e.s = x;
+            e.j = j;
+            lst[pos * 64] = e;
+            ++cnt[st];
+            if constexpr (T16) {
+                // x -> x + 1.002 tau(x) is monotone, so the threshold of the running minimum is
+                // the minimum of the thresholds: no separate m1 register
+                const float d = x + tcl[(2 * st + 1) * 64];
+                const float tn = x + (tcl[(2 * st) * 64] + c1u * (d > 0.0f ? d : 0.0f)) * 1.002f;
+                thr[st] = tn < thr[st] ? tn : thr[st];
+            } else if (x < m1[st]) {
+                m1[st] = x;
+                thr[st] = x + tau_of(tc[st], x) * 1.002f;   // a hair wider than K5's own tau
             }
         }
     };
-    auto epilogue = [&](const AccSet &acc, int blk_global) __attribute__((always_inline)) {
-        static_for<QB>([&](auto qb_c) __attribute__((always_inline)) {
-            epilogue1(acc.template at<decltype(qb_c)::value>(), blk_global, qb_c);
-        });
+    // minimum of the finished scores of one ref block for lane state st
+    auto tile_min = [&](const typename OP::Acc &acc, auto st_c) __attribute__((always_inline)) -> float {
+        constexpr int st = decltype(st_c)::value;
+        if constexpr (T16) {
+            const f32x4 &lo = acc.template at<0, st>();   // refs 4 g + i
+            const f32x4 &hi = acc.template at<1, st>();   // refs 16 + 4 g + i
+            const float t0 = fminf(fminf(lo[0], lo[1]), lo[2]);
+            const float t1 = fminf(fminf(lo[3], hi[0]), hi[1]);
+            return fminf(fminf(t0, t1), fminf(hi[2], hi[3]));
+        } else {
+            const f32x16 &t = acc.template at<st>();
+            const float t0 = fminf(fminf(t[0], t[1]), t[2]);
+            const float t1 = fminf(fminf(t[3], t[4]), t[5]);
+            const float t2 = fminf(fminf(t[6], t[7]), t[8]);
+            const float t3 = fminf(fminf(t[9], t[10]), t[11]);
+            const float t4 = fminf(fminf(t[12], t[13]), t[14]);
+            return fminf(fminf(fminf(t0, t1), t[15]), fminf(fminf(t2, t3), t4));
+        }
     };
-    auto mma_all = [&](AccSet &acc, const float4 &frag, auto b_c) __attribute__((always_inline)) {
+    // slow path of one state: every score of the block against the lane's threshold
+    auto record_all = [&](const typename OP::Acc &acc, int blk_global, auto st_c) __attribute__((always_inline)) {
+        constexpr int st = decltype(st_c)::value;
+        if constexpr (T16) {
+            const f32x4 &lo = acc.template at<0, st>();
+            const f32x4 &hi = acc.template at<1, st>();
+            const int jbase = blk_global * 32 + 4 * (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) record(st_c, lo[r], jbase + r);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) record(st_c, hi[r], jbase + 16 + r);
+        } else {
+            const f32x16 &t = acc.template at<st>();
+            const int jbase = blk_global * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) record(st_c, t[r], jbase + (r & 3) + 8 * (r >> 2));
+        }
+    };
+    // record collection at the end of a ref block
+    auto epilogue = [&](const typename OP::Acc &acc, int blk_global) __attribute__((always_inline)) {
+        if constexpr ((kAblate & 2) != 0) {   // diagnostic: keep the accumulators alive, collect nothing
+            static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
+                constexpr int st = decltype(st_c)::value;
+                if constexpr (T16) {
+                    const f32x4 lo = acc.template at<0, st>(), hi = acc.template at<1, st>();
+                    asm volatile("" ::"v"(lo), "v"(hi));
+                } else {
+                    const f32x16 t = acc.template at<st>();
+                    asm volatile("" ::"v"(t));
+                }
+            });
+            return;
+        }
+        if constexpr (T16) {
+            // four states per lane: ONE wave-uniform branch for the common case (no lane of the
+            // wave has a record in any of its four tiles), then per state inside
+            OP::mma16_fence(const_cast<typename OP::Acc &>(acc));
+            float tm[NS];
+            bool any = false;
+            static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
+                constexpr int st = decltype(st_c)::value;
+                tm[st] = tile_min(acc, st_c);
+                any = any || tm[st] <= thr[st];
+            });
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+                static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
+                    constexpr int st = decltype(st_c)::value;
+                    if (__builtin_amdgcn_ballot_w64(tm[st] <= thr[st]) != 0ull) record_all(acc, blk_global, st_c);
+                });
+            }
+        } else {
+            static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
+                constexpr int st = decltype(st_c)::value;
+                const float tm = tile_min(acc, st_c);
+                if (__builtin_amdgcn_ballot_w64(tm <= thr[st]) != 0ull)   // rare: ~ln(n) tiles per lane
+                    record_all(acc, blk_global, st_c);
+            });
+        }
+    };
+    auto mma_all = [&](typename OP::Acc &acc, const float4 &frag, auto b_c) __attribute__((always_inline)) {
         constexpr int b = decltype(b_c)::value;
-        static_for<QB>([&](auto qc) __attribute__((always_inline)) {
-            constexpr int qb = decltype(qc)::value;
-            acc.template at<qb>() = OP::mma(frag, bq[qb][b], acc.template at<qb>());
-        });
+        if constexpr (T16) {
+            constexpr int ks = b >> 1, rt = b & 1;   // fragment b = k-step ks of ref tile rt
+            static_for<4>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int qt = decltype(qc)::value;
+                if constexpr (ks == 0) OP::mma16_seed(frag, bq[qt][0], acc.template at<rt, qt>(), rt == 0 ? nseed0 : nseed1);
+                else OP::mma16(frag, bq[qt][ks], acc.template at<rt, qt>());
+            });
+        } else {
+            static_for<QB>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int qb = decltype(qc)::value;
+                acc.template at<qb>() = OP::mma(frag, bq[qb][b], acc.template at<qb>());
+            });
+        }
     };
 
     // ---- the software pipeline of one barrier interval -----------------------------------
@@ -360,9 +561,14 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     constexpr int RING = PF < 4 ? 4 : 8;
     constexpr int LAGOFF = SPB / 2;
     static_assert(PF < RING && 32 % RING == 0 && PF <= LAGOFF, "prefetch ring");
-    AccSet acc;
+    typename OP::Acc acc;
+    if constexpr (T16) {
+        const f32x4 inf4 = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+        acc.t00 = acc.t01 = acc.t02 = acc.t03 = acc.t10 = acc.t11 = acc.t12 = acc.t13 = inf4;
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc.v0[r] = acc.v1[r] = __builtin_inff();
+        for (int r = 0; r < 16; ++r) acc.v0[r] = acc.v1[r] = __builtin_inff();
+    }
     float4 fr[RING];
 
     auto frag_ptr = [&](const char *slot, int blk, int f) __attribute__((always_inline)) {
@@ -370,8 +576,9 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     };
 
     // s: slot index relative to slot0; cur/prev/nxt: ring images of slots s, s-1, s+1
-    auto interval = [&](auto lag_c, int s, const char *cur, const char *prev, const char *nxt) __attribute__((always_inline)) {
+    auto interval = [&](auto lag_c, auto dph_c, int s, const char *cur, const char *prev, const char *nxt) __attribute__((always_inline)) {
         constexpr int LAG = decltype(lag_c)::value;
+        constexpr int DPH = decltype(dph_c)::value;   // DMA phase: the SIMD partners issue at different steps
         const bool first = s == 0;
         const int blk0_global = (slot0 + s) * BPS;
         // compile-time schedule: step t works on position u = t - LAG * LAGOFF of the slot's
@@ -393,7 +600,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             // for the two SIMD partners (an LDS-DMA issue stalls the issuing wave ~100 cycles;
             // past the end of the shard it reads the image's padding)
             if constexpr ((kAblate & 16) == 0) {
-                constexpr int d0 = LAG == 0 ? 2 : 16;
+                constexpr int d0 = DPH == 0 ? 2 : 16;
                 constexpr int sp = (F_PPW + 1) * 2 <= 14 ? 2 : 1;   // steps between pieces
                 static_assert(d0 + sp * (F_PPW + 1) <= 32, "DMA pieces must fit the interval");
                 if constexpr (t >= d0 && t < d0 + sp * (F_PPW + 1) && (t - d0) % sp == 0)
@@ -418,10 +625,11 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
 
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    const bool half = wave >= F_NW / 2;   // wave-uniform: the second wave of each SIMD
 #ifdef NNS_F_NOLAG
     const bool lag = false;   // diagnostic: SIMD partners in lock-step
 #else
-    const bool lag = wave >= F_NW / 2;   // wave-uniform
+    const bool lag = OP::kLag && half;
 #endif
     auto ring = [&](int s) __attribute__((always_inline)) { return smem + ((s + F_D) & (F_D - 1)) * F_SLOT_BYTES; };
     static_assert((F_D & (F_D - 1)) == 0, "ring depth must be a power of two");
@@ -444,8 +652,9 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             // everyone's share of slot s+1 has landed; everyone is done with slot s-2
             __builtin_amdgcn_s_barrier();
         }
-        if (!lag) interval(I0{}, s, ring(s), ring(s - 1), ring(s + 1));
-        else interval(I1{}, s, ring(s), ring(s - 1), ring(s + 1));
+        if (!half) interval(I0{}, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
+        else if (lag) interval(I1{}, I1{}, s, ring(s), ring(s - 1), ring(s + 1));
+        else interval(I0{}, I1{}, s, ring(s), ring(s - 1), ring(s + 1));
     }
     if (lag) {   // the lagging half block of the last slot; its first PF fragments are in the ring
         const char *lastp = ring(ns - 1);
@@ -457,7 +666,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         epilogue(acc, (slot0 + ns) * BPS - 1);
     }
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) a.counts[(lblk0 + qb) * 64 + lane] = cnt[qb];
+    for (int st = 0; st < NS; ++st) a.counts[(lblk0 + st) * 64 + lane] = cnt[st];
     if (a.stamps && threadIdx.x == 0) {
         unsigned long long *o = a.stamps + 4 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
         o[0] = st_t0;
@@ -485,7 +694,7 @@ __global__ __launch_bounds__(64) void mfma_selftest_kernel(int kt, int bf16, con
             const int kk = 8 * (s >> 2) + 4 * h + (s & 3);   // same k permutation as the image
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i * kt + kk], b[i * kt + kk], acc, 0, 0, 0);
         }
-    } else {
+    } else if (bf16 == 1) {
         for (int s = 0; s < kt / 16; ++s) {
             bf16x8 av, bv;
 #pragma unroll
@@ -495,6 +704,28 @@ __global__ __launch_bounds__(64) void mfma_selftest_kernel(int kt, int bf16, con
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
         }
+    } else {
+        // bf16 == 2: the same 32x32 product as four 16x16 tiles of v_mfma_f32_16x16x32_bf16, with
+        // the operand / result lane mapping the filter's OpBF16 and K2's order 1 / 2 images assume
+        const int c = lane & 15, g = lane >> 4;
+        for (int rt = 0; rt < 2; ++rt)
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = c0[16 * rt + 4 * g + e];
+                for (int ks = 0; ks < kt / 32; ++ks) {
+                    bf16x8 av, bv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        av[e] = (__bf16)a[(16 * rt + c) * kt + 32 * ks + 8 * g + e];
+                        bv[e] = (__bf16)b[(16 * qt + c) * kt + 32 * ks + 8 * g + e];
+                    }
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, t, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[(16 * rt + 4 * g + e) * 32 + 16 * qt + c] = t[e];
+            }
+        return;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i] = acc[r];
@@ -524,7 +755,8 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g)
     }
     g->bf16 = bf16 ? 1 : 0;
     g->kt = kt;
-    const int qw = 32 * (bf16 ? OpBF16::kQB * OpBF16::kNW : OpF32::kQB * OpF32::kNW);   // queries per workgroup
+    g->lpq = (bf16 && OpBF16Active::kTile16) ? 4 : 2;
+    const int qw = 32 * (bf16 ? OpBF16Active::kQB * OpBF16Active::kNW : OpF32::kQB * OpF32::kNW);   // queries per workgroup
     g->m_pad = divup(m, qw) * qw;
     const int slot_pts = (kt == 32) ? 256 : 64;   // refs per ring slot (32 fragment steps)
     g->n_pad = divup(n, slot_pts) * slot_pts;
@@ -534,14 +766,14 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g)
     // 256 workgroups and a round that is mostly empty costs as much as a full one.  Choose the
     // number of ref-range splits that minimises rounds x (work per workgroup), i.e.
     // ceil(qgroups * s / 256) / s, with a small per-split charge (prologue, lists, merge) and a
-    // cap on the candidate-list memory (1 KiB per query per split).
+    // cap on the candidate-list memory (512 B per lane-list: 1 or 2 KiB per query per split).
     int splits = 1;
     {
         const int64_t list_cap = (int64_t)2 << 30;
         double best_cost = 1e30;
         for (int sp = 1; sp <= 64; ++sp) {
             if (sp > g->total_slots) break;
-            if (sp > 1 && (int64_t)sp * g->m_pad * 1024 > list_cap) break;
+            if (sp > 1 && (int64_t)sp * g->m_pad * g->lpq * 512 > list_cap) break;
             const int rounds = divup(g->qgroups * sp, 256);
             const double cost = (double)rounds / sp * (1.0 + 0.004 * sp);
             if (cost < best_cost - 1e-12) {
@@ -563,15 +795,17 @@ template <class OP>
 static int launch_filter_t(const FilterGeom &g, const FilterArgs &args, hipStream_t st)
 {
     auto kern = filter_kernel<OP>;
+    // 16x16 tiles: + 2 KiB per wave for the lanes' tau constants
+    constexpr int lds_bytes = F_LDS_BYTES + (OP::kTile16 ? OP::kNW * 2048 : 0);
     // > 64 KiB of dynamic LDS needs the opt-in, once per device
     static bool attr_set[64] = {};
     int dev = 0;
     NNS_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        NNS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES));
+        NNS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(g.qgroups, g.splits), dim3(OP::kNW * 64), F_LDS_BYTES, st, args);
+    hipLaunchKernelGGL(kern, dim3(g.qgroups, g.splits), dim3(OP::kNW * 64), lds_bytes, st, args);
     NNS_HIP(hipGetLastError());
     return NNS_OK;
 }
@@ -597,7 +831,7 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
     const char *clk = getenv("NNS_FILTER_CLOCK");
     const size_t nwg = (size_t)g.qgroups * g.splits;
     if (clk && atoi(clk)) NNS_HIP(hipMalloc(&a.stamps, nwg * 4 * sizeof(unsigned long long)));
-    const int rc = g.bf16 ? launch_filter_t<OpBF16>(g, a, st)
+    const int rc = g.bf16 ? launch_filter_t<OpBF16Active>(g, a, st)
                           : (g.kt == 32 ? launch_filter_t<OpF32K32>(g, a, st) : launch_filter_t<OpF32>(g, a, st));
     if (a.stamps) {   // diagnostic: synchronous read-out, median clock over workgroups
         std::vector<unsigned long long> h(nwg * 4);

@@ -74,22 +74,23 @@ __device__ __forceinline__ float v0_distance(const T *qi, const T *rj, int k, bo
 
 template <typename T>
 __global__ __launch_bounds__(256) void finalize_kernel(
-    int kt, int bf16, int m_pad, int splits, int k, int m, int n, const T *__restrict__ q,
+    int kt, int bf16, int lpq, int m_pad, int splits, int k, int m, int n, const T *__restrict__ q,
     const T *__restrict__ r, const CandEntry *__restrict__ lists, const int *__restrict__ counts,
     const float *__restrict__ qnorm, DevScalars *__restrict__ scal, int64_t index_base,
     nns_key *__restrict__ keys, int *__restrict__ amb_list)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
+    const int ush = lpq == 4 ? 4 : 5, qmask = (1 << ush) - 1;   // queries per list unit: 16 or 32
 
     bool fallback = scal->q_maxabs_bits >= kHugeBits || scal->r_maxabs_bits >= kHugeBits;
     float a = __builtin_inff();
     if (!fallback) {
         for (int s = 0; s < splits; ++s)
-            for (int h = 0; h < 2; ++h) {
-                // [split][query block][entry][lane], lane = 32h + (i & 31)
-                const size_t lblk = (size_t)s * (m_pad / 32) + (i >> 5);
-                const int ln = 32 * h + (i & 31);
+            for (int h = 0; h < lpq; ++h) {
+                // [split][unit][entry][lane]: unit = 64 / lpq queries, lane = qpu * h + (i % qpu)
+                const size_t lblk = (size_t)s * (m_pad >> ush) + (i >> ush);
+                const int ln = (h << ush) + (i & qmask);
                 const int cw = counts[lblk * 64 + ln];
                 if (cw & kCandOverflow) fallback = true;
                 const int c = (cw & kCandCountMask) < kCandCap ? (cw & kCandCountMask) : kCandCap;
@@ -106,9 +107,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(
         const T *qi = q + (size_t)i * k;
         const bool vec = (k & 3) == 0 && (((uintptr_t)q | (uintptr_t)r) & (4 * sizeof(T) - 1)) == 0;
         for (int s = 0; s < splits; ++s)
-            for (int h = 0; h < 2; ++h) {
-                const size_t lblk = (size_t)s * (m_pad / 32) + (i >> 5);
-                const int ln = 32 * h + (i & 31);
+            for (int h = 0; h < lpq; ++h) {
+                const size_t lblk = (size_t)s * (m_pad >> ush) + (i >> ush);
+                const int ln = (h << ush) + (i & qmask);
                 const int cw = counts[lblk * 64 + ln] & kCandCountMask;
                 const int c = cw < kCandCap ? cw : kCandCap;
                 const CandEntry *l = lists + lblk * (kCandCap * 64) + ln;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(
 // are reduced across the wave with packed-key / float shuffles.
 template <typename T>
 __global__ __launch_bounds__(256) void finalize_wave_kernel(
-    int kt, int bf16, int m_pad, int splits, int k, int m, int n, const T *__restrict__ q,
+    int kt, int bf16, int lpq, int m_pad, int splits, int k, int m, int n, const T *__restrict__ q,
     const T *__restrict__ r, const CandEntry *__restrict__ lists, const int *__restrict__ counts,
     const float *__restrict__ qnorm, DevScalars *__restrict__ scal, int64_t index_base,
     nns_key *__restrict__ keys, int *__restrict__ amb_list)
@@ -146,14 +147,15 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);   // wave-uniform query
     if (i >= m) return;
-    const int nlists = 2 * splits;
+    const int nlists = lpq * splits;
+    const int ush = lpq == 4 ? 4 : 5, qmask = (1 << ush) - 1, lsh = lpq == 4 ? 2 : 1;
     bool fallback = scal->q_maxabs_bits >= kHugeBits || scal->r_maxabs_bits >= kHugeBits;
     float a = __builtin_inff();
     int over = 0;
     for (int l = lane; l < nlists; l += 64) {
-        const int s = l >> 1, h = l & 1;
-        const size_t lblk = (size_t)s * (m_pad / 32) + (i >> 5);
-        const int ln = 32 * h + (i & 31);
+        const int s = l >> lsh, h = l & (lpq - 1);
+        const size_t lblk = (size_t)s * (m_pad >> ush) + (i >> ush);
+        const int ln = (h << ush) + (i & qmask);
         const int cw = counts[lblk * 64 + ln];
         if (cw & kCandOverflow) over = 1;
         const int c = (cw & kCandCountMask) < kCandCap ? (cw & kCandCountMask) : kCandCap;
@@ -174,9 +176,9 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
         const T *qi = q + (size_t)i * k;
         const bool vec = (k & 3) == 0 && (((uintptr_t)q | (uintptr_t)r) & (4 * sizeof(T) - 1)) == 0;
         for (int l = lane; l < nlists; l += 64) {
-            const int s = l >> 1, h = l & 1;
-            const size_t lblk = (size_t)s * (m_pad / 32) + (i >> 5);
-            const int ln = 32 * h + (i & 31);
+            const int s = l >> lsh, h = l & (lpq - 1);
+            const size_t lblk = (size_t)s * (m_pad >> ush) + (i >> ush);
+            const int ln = (h << ush) + (i & qmask);
             const int cw = counts[lblk * 64 + ln] & kCandCountMask;
             const int c = cw < kCandCap ? cw : kCandCap;
             const CandEntry *lp = lists + lblk * (kCandCap * 64) + ln;
@@ -214,21 +216,21 @@ int launch_finalize(const FilterGeom &g, int k, int m, int n, const void *q, con
     if (g.splits >= 4) {   // few queries, many lists per query: one wave per query
         if (g.bf16)
             hipLaunchKernelGGL(finalize_wave_kernel<uint16_t>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, 1,
-                               g.m_pad, g.splits, k, m, n, (const uint16_t *)q, (const uint16_t *)r, lists,
+                               g.lpq, g.m_pad, g.splits, k, m, n, (const uint16_t *)q, (const uint16_t *)r, lists,
                                counts, qnorm, scal, index_base, keys, amb_list);
         else
-            hipLaunchKernelGGL(finalize_wave_kernel<float>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, 0, g.m_pad,
+            hipLaunchKernelGGL(finalize_wave_kernel<float>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, 0, g.lpq, g.m_pad,
                                g.splits, k, m, n, (const float *)q, (const float *)r, lists, counts, qnorm, scal,
                                index_base, keys, amb_list);
         NNS_HIP(hipGetLastError());
         return NNS_OK;
     }
     if (g.bf16)
-        hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(divup(m, 256)), dim3(256), 0, st, g.kt, 1, g.m_pad,
+        hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(divup(m, 256)), dim3(256), 0, st, g.kt, 1, g.lpq, g.m_pad,
                            g.splits, k, m, n, (const uint16_t *)q, (const uint16_t *)r, lists, counts, qnorm,
                            scal, index_base, keys, amb_list);
     else
-        hipLaunchKernelGGL(finalize_kernel<float>, dim3(divup(m, 256)), dim3(256), 0, st, g.kt, 0, g.m_pad,
+        hipLaunchKernelGGL(finalize_kernel<float>, dim3(divup(m, 256)), dim3(256), 0, st, g.kt, 0, g.lpq, g.m_pad,
                            g.splits, k, m, n, (const float *)q, (const float *)r, lists, counts, qnorm, scal,
                            index_base, keys, amb_list);
     NNS_HIP(hipGetLastError());

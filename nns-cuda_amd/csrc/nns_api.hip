@@ -94,7 +94,7 @@ static int prep_refs(nns_index *ix, hipStream_t st)
     const FilterGeom &g = ix->geom;
     NNS_HIP(hipMemsetAsync(ix->scal, 0, sizeof(DevScalars), st));
     if (ix->bf16) {
-        NNS_TRY(launch_prep_image_bf16(ix->k, ix->n, g.n_pad, (const uint16_t *)ix->r_dev, -2.0f, INFINITY,
+        NNS_TRY(launch_prep_image_bf16(NNS_BF16_TILE16 ? 1 : 0, ix->k, ix->n, g.n_pad, (const uint16_t *)ix->r_dev, -2.0f, INFINITY,
                                        ix->rimg, ix->rnorm, &ix->scal->ymax2_bits,
                                        &ix->scal->r_maxabs_bits, st));
         return NNS_OK;
@@ -292,7 +292,7 @@ static int ensure_query_ws(nns_index *ix, int m)
         }
         ix->m_cap = gq.m_pad;
     }
-    const size_t need = (size_t)gq.splits * gq.m_pad * 2;   // lane-lists
+    const size_t need = (size_t)gq.splits * gq.m_pad * gq.lpq;   // lane-lists
     if (need > ix->lists_cap) {
         if (ix->lists) (void)hipDeviceSynchronize();
         pool_free(ix->lists);
@@ -360,7 +360,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
     NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned), st));
     NNS_HIP(hipMemsetAsync(&ix->scal->amb_count, 0, sizeof(int), st));
     if (bf16)
-        NNS_TRY(launch_prep_image_bf16(ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
+        NNS_TRY(launch_prep_image_bf16(NNS_BF16_TILE16 ? 2 : 0, ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
                                        nullptr, &ix->scal->q_maxabs_bits, st));
     else
         NNS_TRY(launch_prep_image(ix->k, g.kt, m, g.m_pad, (const float *)q_dev, ix->mean, 1.0f, 0.0f,
@@ -368,6 +368,20 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
     if (prof) (void)hipEventRecord(ix->ev[EV_QPREP], st);
     NNS_TRY(launch_filter(g, ix->qimg, ix->rimg, ix->rnorm, ix->qnorm, ix->scal, ix->lists, ix->counts, st));
     if (prof) (void)hipEventRecord(ix->ev[EV_FILTER], st);
+    // tuning diagnostic for ablated filter builds (-DNNS_FILTER_ABLATE: empty candidate lists would
+    // send every query to the exact scan): stop after the filter; the keys are NOT results
+    static const bool filter_only = getenv("NNS_DIAG_FILTER_ONLY") != nullptr;
+    if (filter_only) {
+        NNS_TRY(launch_keys_fill(keys_dev, m, NNS_KEY_NONE, st));
+        if (prof) {
+            (void)hipEventRecord(ix->ev[EV_FINAL], st);
+            (void)hipEventRecord(ix->ev[EV_RERANK], st);
+            (void)hipEventRecord(ix->ev[EV_END], st);
+        }
+        ix->last_path = NNS_PATH_MFMA;
+        ix->searched = true;
+        return NNS_OK;
+    }
     NNS_TRY(launch_finalize(g, ix->k, m, ix->n, q_dev, ix->r_dev, ix->lists, ix->counts, ix->qnorm,
                             ix->scal, ix->base, keys_dev, ix->amb_list, st));
     if (prof) (void)hipEventRecord(ix->ev[EV_FINAL], st);
@@ -453,7 +467,8 @@ int nns_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset, v
 
 int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const float *c0, float *out)
 {
-    if (kt <= 0 || (kt & 15) || !a || !b || !c0 || !out) return NNS_ERR_INVALID;
+    if (kt <= 0 || (kt & 15) || (bf16 == 2 && (kt & 31)) || bf16 < 0 || bf16 > 2 || !a || !b || !c0 || !out)
+        return NNS_ERR_INVALID;
     NNS_TRY(ensure_device_ok(0));
     float *d = nullptr;
     const size_t na = (size_t)32 * kt, total = 2 * na + 32 + 1024;

@@ -70,8 +70,16 @@ __device__ __forceinline__ float v0_step(float sum, float q, float r)
 // (v_mfma_f32_32x32x2_f32: lane supplies A[i = lane&31][k = lane>>5]).
 constexpr int kBlockPts = 32;
 
+// bf16 filter MFMA shape: 1 = v_mfma_f32_16x16x32_bf16 (the product: the chip clocks ~14 % higher
+// on it under load), 0 = v_mfma_f32_32x32x16_bf16 (A/B builds).  Fixes the bf16 tile-image order
+// (prep_kernels.hip) and the lanes a query's candidate lists live on (finalize.hip).
+#ifndef NNS_BF16_TILE16
+#define NNS_BF16_TILE16 1
+#endif
+
 struct FilterGeom {
     int bf16;             // 1: bf16 operands (K4), 0: fp32 operands (K3)
+    int lpq;              // lanes (= private candidate lists) per query and split: 2, or 4 with 16x16 tiles
     int kt;               // K of the tile (k padded up with zeros)
     int m_pad;            // queries padded to the workgroup's query count
     int n_pad;            // refs padded to a whole ring slot
@@ -180,7 +188,9 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts,
 
 // bf16 points (raw uint16 bits) -> bf16 tile image [blk][16][64 lanes][8 bf16], value * scale
 // (scale = 1 or -2, exact), fp32 norms of the UNcentred points, max-|v| word
-int launch_prep_image_bf16(int k, int npts, int npts_pad, const uint16_t *pts, float scale,
+// order: 0 = 32x32x16 operands; 16x16x32 operands: 1 = refs (fragment 2 ks + tile), 2 = queries
+// (fragment 8 tile + ks)
+int launch_prep_image_bf16(int order, int k, int npts, int npts_pad, const uint16_t *pts, float scale,
                            float pad_norm, void *img, float *norms, unsigned *max_norm_bits,
                            unsigned *maxabs_bits, hipStream_t st);
 

@@ -279,7 +279,12 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, c
 // lane (i = lane & 31, h = lane >> 5) of step s holds dims 16s + 8h .. 16s + 8h + 7 of point
 // i — one v_mfma_f32_32x32x16_bf16 operand per ds_read_b128.  No centring (a centred bf16
 // value would need a second rounding); the scale (-2 for refs) is exact in bf16.
-__global__ __launch_bounds__(256) void image_bf16_kernel(int k, int npts, const uint16_t *__restrict__ pts,
+//
+// order 1 / 2 (v_mfma_f32_16x16x32_bf16 operands): a fragment is one 16-point tile t x one k-step
+// ks of 32 dims; lane l holds dims 32 ks + 8 (l >> 4) .. + 7 of point 16 t + (l & 15).  Refs
+// (order 1) store fragment 2 ks + t (the filter alternates the two ref tiles), queries (order 2)
+// fragment 8 t + ks (a wave keeps all k-steps of its four query tiles in registers).
+__global__ __launch_bounds__(256) void image_bf16_kernel(int order, int k, int npts, const uint16_t *__restrict__ pts,
                                                          float scale, float pad_norm,
                                                          uint16_t *__restrict__ img, float *__restrict__ norms,
                                                          unsigned *__restrict__ max_norm_bits,
@@ -349,8 +354,16 @@ __global__ __launch_bounds__(256) void image_bf16_kernel(int k, int npts, const 
     uint4 *out = reinterpret_cast<uint4 *>(img + (size_t)blk * 32 * KT);
     for (int f = tid; f < 16 * 64; f += 256) {
         const int s = f >> 6, lane = f & 63;
-        const int h = lane >> 5, i = lane & 31;
-        const uint4 sv = *reinterpret_cast<const uint4 *>(&tile[i * LD + 16 * s + 8 * h]);
+        int i, d0;   // point of the block and first dim of this lane's 8
+        if (order == 0) {
+            i = lane & 31;
+            d0 = 16 * s + 8 * (lane >> 5);
+        } else {
+            const int t = order == 1 ? (s & 1) : (s >> 3), ks = order == 1 ? (s >> 1) : (s & 7);
+            i = 16 * t + (lane & 15);
+            d0 = 32 * ks + 8 * (lane >> 4);
+        }
+        const uint4 sv = *reinterpret_cast<const uint4 *>(&tile[i * LD + d0]);
         const unsigned in[4] = {sv.x, sv.y, sv.z, sv.w};
         unsigned w[4];
 #pragma unroll
@@ -370,11 +383,11 @@ __global__ __launch_bounds__(256) void image_bf16_kernel(int k, int npts, const 
     if ((tid & 63) == 0 && maxabs_bits) max_word(maxabs_bits, mx);
 }
 
-int launch_prep_image_bf16(int k, int npts, int npts_pad, const uint16_t *pts, float scale, float pad_norm,
+int launch_prep_image_bf16(int order, int k, int npts, int npts_pad, const uint16_t *pts, float scale, float pad_norm,
                            void *img, float *norms, unsigned *max_norm_bits, unsigned *maxabs_bits,
                            hipStream_t st)
 {
-    hipLaunchKernelGGL(image_bf16_kernel, dim3(npts_pad / 32), dim3(256), 0, st, k, npts, pts, scale, pad_norm,
+    hipLaunchKernelGGL(image_bf16_kernel, dim3(npts_pad / 32), dim3(256), 0, st, order, k, npts, pts, scale, pad_norm,
                        (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
     NNS_HIP(hipGetLastError());
     return NNS_OK;

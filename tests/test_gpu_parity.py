@@ -59,15 +59,18 @@ def test_mfma_is_an_fmaf_chain(pkg, orc):
                 assert out[i, j].view(np.uint32) == want.view(np.uint32), (kt, i, j)
 
 
-def test_bf16_mfma_error_model(pkg, orc):
-    """v_mfma_f32_32x32x16_bf16 (fp32 accumulate) vs fp64 on bf16-representable data: the
-    error must stay well inside the 2u-per-add model tau assumes for the bf16 path."""
+@pytest.mark.parametrize("shape", [2, 1])
+def test_bf16_mfma_error_model(pkg, orc, shape):
+    """bf16 MFMA (fp32 accumulate) vs fp64 on bf16-representable data: the error must stay well
+    inside the 2u-per-add model tau assumes for the bf16 path.  shape 2 = the filter's
+    v_mfma_f32_16x16x32_bf16 with the operand / result lane mapping K2's images and the filter's
+    epilogue assume (a wrong mapping shows up as O(1) errors here); shape 1 = 32x32x16."""
     rng = np.random.default_rng(2)
     kt = 256
     a = orc.round_bf16((rng.random((32, kt), dtype=np.float32)) * -2.0)
     b = orc.round_bf16(rng.random((32, kt), dtype=np.float32))
     c0 = (a.astype(np.float64) ** 2).sum(1).astype(np.float32) / 4
-    out = pkg.selftest_mfma(a, b, c0, bf16=True)
+    out = pkg.selftest_mfma(a, b, c0, bf16=shape)
     exact = c0.astype(np.float64)[:, None] + a.astype(np.float64) @ b.astype(np.float64).T
     mag = np.abs(c0.astype(np.float64))[:, None] + np.abs(a.astype(np.float64)) @ np.abs(b.astype(np.float64)).T
     u = 2.0 ** -24
