@@ -182,7 +182,10 @@ using OpF32K32 = OpF32T<4>;    // KT = 32: the mid-range dimensionalities (k = 8
 struct OpBF16 {
     static constexpr int kSPB = 16;
     static constexpr bool kTile16 = true;
-    static constexpr bool kLag = false;       // measured on C5: lock-step partners 80.1 ms, lagged 83.3
+#ifndef NNS_F_T16_LAG
+#define NNS_F_T16_LAG 0
+#endif
+    static constexpr bool kLag = NNS_F_T16_LAG != 0;   // measured on C5: lock-step partners 80.1 ms, lagged 83.3
     using Acc = AccSet16;
     static constexpr int kQB = 2;             // 64 queries per wave = 4 query tiles
     static constexpr int kNW = NNS_F_NW_BF16;
@@ -195,7 +198,7 @@ struct OpBF16 {
     // instead of 32), which spills the resident query operands.  The compiler does not see MFMA
     // hazards of an asm statement; the kernel keeps them by construction: an accumulator is
     // re-used as srcC only 8 MFMAs later, and VALU reads of it (the epilogue) wait behind an
-    // explicit s_nop (mma16_fence).
+    // the epilogue's fences (mma16_fence_lo / _hi).
     __device__ static __forceinline__ void mma16(const float4 &a, const float4 &b, f32x4 &acc)
     {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
@@ -209,14 +212,23 @@ struct OpBF16 {
                      : "=&v"(acc)
                      : "v"(__builtin_bit_cast(f32x4, a)), "v"(__builtin_bit_cast(f32x4, b)), "v"(c));
     }
-    // Before VALU touches just-written accumulators (passes + 3 wait states; 13 covers 8 passes).
-    // The accumulators are in/out operands so that every later read of them is ordered behind
-    // the wait — to the compiler an asm MFMA's result is ready at once, and it would otherwise
-    // hoist the epilogue's v_min3 right behind the MFMAs (stale reads: seen as wrong indices).
-    __device__ static __forceinline__ void mma16_fence(AccSet16 &c)
+    // VALU may read an accumulator 8 wait states after the MFMA that wrote it issued (what hipcc
+    // inserts behind the builtin: s_nop 7).  To the compiler an asm MFMA's result is ready at
+    // once, and it would hoist the epilogue's v_min3 right behind the MFMAs (stale reads: seen as
+    // wrong indices), so the epilogue orders its reads with two empty asm fences that take the
+    // accumulators as in/out operands:
+    //   fence_lo: behind the block's last MFMAs (volatile asm keeps program order).  The ref tile
+    //             0 accumulators were finished a whole step (4 MFMAs, 64 cycles) earlier.
+    //   fence_hi: behind the 8 VALU instructions that reduce the four tile-0 accumulators (its
+    //             other operands) + 2 wait states of margin: ref tile 1 is readable after it.
+    __device__ static __forceinline__ void mma16_fence_lo(AccSet16 &c)
     {
-        asm volatile("s_nop 7\n\ts_nop 4"
-                     : "+v"(c.t00), "+v"(c.t01), "+v"(c.t02), "+v"(c.t03), "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13));
+        asm volatile("" : "+v"(c.t00), "+v"(c.t01), "+v"(c.t02), "+v"(c.t03));
+    }
+    __device__ static __forceinline__ void mma16_fence_hi(AccSet16 &c, float &m0, float &m1, float &m2, float &m3)
+    {
+        asm volatile("s_nop 1"
+                     : "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13), "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3));
     }
 };
 
@@ -507,12 +519,19 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         if constexpr (T16) {
             // four states per lane: ONE wave-uniform branch for the common case (no lane of the
             // wave has a record in any of its four tiles), then per state inside
-            OP::mma16_fence(const_cast<typename OP::Acc &>(acc));
+            typename OP::Acc &wacc = const_cast<typename OP::Acc &>(acc);
             float tm[NS];
+            OP::mma16_fence_lo(wacc);
+            static_for<NS>([&](auto st_c) __attribute__((always_inline)) {   // 2 VALU per state
+                const f32x4 &lo = acc.template at<0, decltype(st_c)::value>();
+                tm[decltype(st_c)::value] = fminf(fminf(fminf(lo[0], lo[1]), lo[2]), lo[3]);
+            });
+            OP::mma16_fence_hi(wacc, tm[0], tm[1], tm[2], tm[3]);
             bool any = false;
             static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
                 constexpr int st = decltype(st_c)::value;
-                tm[st] = tile_min(acc, st_c);
+                const f32x4 &hi = acc.template at<1, st>();
+                tm[st] = fminf(fminf(fminf(fminf(tm[st], hi[0]), hi[1]), hi[2]), hi[3]);
                 any = any || tm[st] <= thr[st];
             });
             if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
