@@ -175,22 +175,26 @@ using OpF32K32 = OpF32T<4>;    // KT = 32: the mid-range dimensionalities (k = 8
 // but the chip holds a ~14 % higher clock on it under this loop's load (measured here on C5:
 // in-kernel clock 2.05 vs 1.80 GHz, filter 70 vs 80 ms in the bare loop; MI355X guide, 'DVFS
 // give-back' item 7).  A step = one 1 KiB fragment (16 refs x 32 dims) x the wave's FOUR
-// 16-query tiles; step b = 2 * ks + rt walks the 8 k-steps of the two 16-ref tiles alternately.
+// 16-query tiles; step b = 8 * rt + ks: the 8 k-steps of ref tile 0, then those of ref tile 1.
 // C layout: lane l holds query column l & 15 and ref rows 4 * (l >> 4) .. + 3 of each tile, so a
 // lane carries four queries (one per query tile) x 8 refs per block, and a query's refs are
 // spread over the four lanes l & 15 + 16 g — four lane-private candidate lists per query.
+//
+// The record collection of one ref tile runs INSIDE the MFMA stream of the other: a burst of
+// ~20 VALU instructions at a block boundary keeps the SIMD's vector issue port for ~80 cycles
+// with no MFMA issued (neither by this wave nor by its SIMD partner: lagging the partners did
+// not hide it, measured), which cost 7-9 % of this kernel.  Two v_min per MFMA gap fit the 8
+// issue cycles a 16x16x32 leaves free, so the reduction of tile rt's finished scores is spread
+// over k-step 1 of tile 1 - rt, and the threshold test + (rare) slow path follow at k-step 2.
 struct OpBF16 {
     static constexpr int kSPB = 16;
     static constexpr bool kTile16 = true;
-#ifndef NNS_F_T16_LAG
-#define NNS_F_T16_LAG 0
-#endif
-    static constexpr bool kLag = NNS_F_T16_LAG != 0;   // measured on C5: lock-step partners 80.1 ms, lagged 83.3
+    static constexpr bool kLag = false;       // lock-step SIMD partners (lagging them: +1..4 % time on C5)
     using Acc = AccSet16;
     static constexpr int kQB = 2;             // 64 queries per wave = 4 query tiles
     static constexpr int kNW = NNS_F_NW_BF16;
 #ifndef NNS_F_PF_BF16
-#define NNS_F_PF_BF16 2
+#define NNS_F_PF_BF16 1   // (2 fits the 32x32x16 variant; here it spills three query fragments)
 #endif
     static constexpr int kPrefetch = NNS_F_PF_BF16;
     // Inline asm, accumulating IN PLACE: through the builtin hipcc picks the three-address form
@@ -214,21 +218,13 @@ struct OpBF16 {
     }
     // VALU may read an accumulator 8 wait states after the MFMA that wrote it issued (what hipcc
     // inserts behind the builtin: s_nop 7).  To the compiler an asm MFMA's result is ready at
-    // once, and it would hoist the epilogue's v_min3 right behind the MFMAs (stale reads: seen as
-    // wrong indices), so the epilogue orders its reads with two empty asm fences that take the
-    // accumulators as in/out operands:
-    //   fence_lo: behind the block's last MFMAs (volatile asm keeps program order).  The ref tile
-    //             0 accumulators were finished a whole step (4 MFMAs, 64 cycles) earlier.
-    //   fence_hi: behind the 8 VALU instructions that reduce the four tile-0 accumulators (its
-    //             other operands) + 2 wait states of margin: ref tile 1 is readable after it.
-    __device__ static __forceinline__ void mma16_fence_lo(AccSet16 &c)
+    // once.  In the loop the readers sit a whole step (>= 64 cycles) behind the writers and
+    // __builtin_amdgcn_sched_barrier keeps them there; the kernel's tail reads right behind the
+    // last MFMAs and needs the explicit wait, with the accumulators as in/out operands so that
+    // the reads are ordered behind it.
+    __device__ static __forceinline__ void mma16_tail_fence(AccSet16 &c)
     {
-        asm volatile("" : "+v"(c.t00), "+v"(c.t01), "+v"(c.t02), "+v"(c.t03));
-    }
-    __device__ static __forceinline__ void mma16_fence_hi(AccSet16 &c, float &m0, float &m1, float &m2, float &m3)
-    {
-        asm volatile("s_nop 1"
-                     : "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13), "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3));
+        asm volatile("s_nop 7\n\ts_nop 1" : "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13));
     }
 };
 
@@ -413,13 +409,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // accumulators start at |y'_j|^2 of their rows: rows (r&3) + 8(r>>2) + 4h
     auto seed = [&](typename OP::Acc &acc, const char *slot, int blk) __attribute__((always_inline)) {
         if constexpr (T16) {
-            // rows 16 rt + 4 (lane >> 4) + i of every query tile
-            const float *nrm = reinterpret_cast<const float *>(slot + F_SLOT_COORD) + blk * 32 + 4 * (lane >> 4);
-            // (loaded here, consumed as srcC by the tile's first MFMAs: no register copies)
-            const float4 n0 = *reinterpret_cast<const float4 *>(nrm), n1 = *reinterpret_cast<const float4 *>(nrm + 16);
-            nseed0 = f32x4{n0.x, n0.y, n0.z, n0.w};
-            nseed1 = f32x4{n1.x, n1.y, n1.z, n1.w};
-            return;
+            return;   // (16x16 tiles: seed16 below)
         } else {
         const float *nrm = reinterpret_cast<const float *>(slot + F_SLOT_COORD) + blk * 32 + 4 * h;
 #pragma unroll
@@ -435,6 +425,15 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             });
         }
         }
+    };
+    // 16x16 tiles: the norms of ref tile rt of block blk (rows 16 rt + 4 (lane >> 4) + i), loaded
+    // two steps ahead of the tile's first MFMAs, which take them as srcC (no register copies)
+    auto seed16 = [&](const char *slot, int blk, auto rt_c) __attribute__((always_inline)) {
+        constexpr int rt = decltype(rt_c)::value;
+        const float4 nv = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(slot + F_SLOT_COORD) +
+                                                            blk * 32 + 16 * rt + 4 * (lane >> 4));
+        if constexpr (rt == 0) nseed0 = f32x4{nv.x, nv.y, nv.z, nv.w};
+        else nseed1 = f32x4{nv.x, nv.y, nv.z, nv.w};
     };
     // one finished score x of ref j (slow path): append to the state's candidate ring, tighten
     auto record = [&](auto st_c, float x, int j) __attribute__((always_inline)) {
@@ -517,29 +516,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             return;
         }
         if constexpr (T16) {
-            // four states per lane: ONE wave-uniform branch for the common case (no lane of the
-            // wave has a record in any of its four tiles), then per state inside
-            typename OP::Acc &wacc = const_cast<typename OP::Acc &>(acc);
-            float tm[NS];
-            OP::mma16_fence_lo(wacc);
-            static_for<NS>([&](auto st_c) __attribute__((always_inline)) {   // 2 VALU per state
-                const f32x4 &lo = acc.template at<0, decltype(st_c)::value>();
-                tm[decltype(st_c)::value] = fminf(fminf(fminf(lo[0], lo[1]), lo[2]), lo[3]);
-            });
-            OP::mma16_fence_hi(wacc, tm[0], tm[1], tm[2], tm[3]);
-            bool any = false;
-            static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
-                constexpr int st = decltype(st_c)::value;
-                const f32x4 &hi = acc.template at<1, st>();
-                tm[st] = fminf(fminf(fminf(fminf(tm[st], hi[0]), hi[1]), hi[2]), hi[3]);
-                any = any || tm[st] <= thr[st];
-            });
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-                static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
-                    constexpr int st = decltype(st_c)::value;
-                    if (__builtin_amdgcn_ballot_w64(tm[st] <= thr[st]) != 0ull) record_all(acc, blk_global, st_c);
-                });
-            }
+            // (16x16 tiles retire their ref tiles inside t16_step)
         } else {
             static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
                 constexpr int st = decltype(st_c)::value;
@@ -552,17 +529,63 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     auto mma_all = [&](typename OP::Acc &acc, const float4 &frag, auto b_c) __attribute__((always_inline)) {
         constexpr int b = decltype(b_c)::value;
         if constexpr (T16) {
-            constexpr int ks = b >> 1, rt = b & 1;   // fragment b = k-step ks of ref tile rt
-            static_for<4>([&](auto qc) __attribute__((always_inline)) {
-                constexpr int qt = decltype(qc)::value;
-                if constexpr (ks == 0) OP::mma16_seed(frag, bq[qt][0], acc.template at<rt, qt>(), rt == 0 ? nseed0 : nseed1);
-                else OP::mma16(frag, bq[qt][ks], acc.template at<rt, qt>());
-            });
+            // (16x16 tiles go through t16_step)
         } else {
             static_for<QB>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int qb = decltype(qc)::value;
                 acc.template at<qb>() = OP::mma(frag, bq[qb][b], acc.template at<qb>());
             });
+        }
+    };
+
+    // ---- 16x16 tiles: one step, with the other ref tile's record collection folded in --------
+    float tmh[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // minima of the retiring ref tile, one per state
+    unsigned long long hm[4] = {0ull, 0ull, 0ull, 0ull};
+    // threshold test of the retiring ref tile ot of block oblk: ONE wave-uniform branch for the
+    // common case (no lane has a record in any of its four states), then per state inside
+    auto t16_test = [&](typename OP::Acc &acc, int oblk, auto ot_c) __attribute__((always_inline)) {
+        if constexpr (T16) {
+            constexpr int ot = decltype(ot_c)::value;
+            if ((hm[0] | hm[1] | hm[2] | hm[3]) != 0ull) {
+                const int jbase = oblk * 32 + 16 * ot + 4 * (lane >> 4);
+                static_for<4>([&](auto st_c) __attribute__((always_inline)) {
+                    constexpr int st = decltype(st_c)::value;
+                    if (hm[st] != 0ull) {
+                        const f32x4 &o = acc.template at<ot, st>();
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) record(st_c, o[r], jbase + r);
+                    }
+                });
+            }
+        }
+    };
+    // the four states' lane masks "this lane has a score within its threshold" (v_cmp straight to
+    // SGPR pairs, computed a step before the branch that reads them)
+    auto t16_masks = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) hm[st] = __builtin_amdgcn_ballot_w64(tmh[st] <= thr[st]);
+    };
+    // step b = 8 rt + ks of the block blk_global: the 4 MFMAs of ref tile rt's k-step ks; at
+    // ks = 1 the other tile's four accumulators (finished at its k-step 7, >= 5 MFMAs ago) are
+    // reduced, two v_min behind each MFMA; at ks = 2 they are tested.  The other tile of rt = 0
+    // is tile 1 of the PREVIOUS block (kernel start: +INF accumulators, nothing to record).
+    auto t16_step = [&](typename OP::Acc &acc, const float4 &frag, int blk_global, auto b_c) __attribute__((always_inline)) {
+        if constexpr (T16) {
+            constexpr int b = decltype(b_c)::value;
+            constexpr int rt = b >> 3, ks = b & 7, ot = 1 - rt;
+            static_for<4>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int qt = decltype(qc)::value;
+                if constexpr (ks == 0) OP::mma16_seed(frag, bq[qt][0], acc.template at<rt, qt>(), rt == 0 ? nseed0 : nseed1);
+                else OP::mma16(frag, bq[qt][ks], acc.template at<rt, qt>());
+                if constexpr (ks == 1) {
+                    const f32x4 o = acc.template at<ot, qt>();
+                    if constexpr ((kAblate & 2) != 0) asm volatile("" ::"v"(o));
+                    else tmh[qt] = fminf(fminf(fminf(o[0], o[1]), o[2]), o[3]);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the pair right behind its MFMA
+                }
+            });
+            if constexpr (ks == 1 && (kAblate & 2) == 0) t16_masks();
+            if constexpr (ks == 2 && (kAblate & 2) == 0) t16_test(acc, rt == 0 ? blk_global - 1 : blk_global, std::integral_constant<int, ot>{});
         }
     };
 
@@ -594,6 +617,8 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         return (reinterpret_cast<const float4 *>(slot + blk * BLK_BYTES) + lane) + f * 64;
     };
 
+    using I0c = std::integral_constant<int, 0>;
+    using I1c = std::integral_constant<int, 1>;
     // s: slot index relative to slot0; cur/prev/nxt: ring images of slots s, s-1, s+1
     auto interval = [&](auto lag_c, auto dph_c, int s, const char *cur, const char *prev, const char *nxt) __attribute__((always_inline)) {
         constexpr int LAG = decltype(lag_c)::value;
@@ -625,15 +650,24 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                 if constexpr (t >= d0 && t < d0 + sp * (F_PPW + 1) && (t - d0) % sp == 0)
                     issue_piece(s + 2, (t - d0) / sp);
             }
-            if constexpr (b == 0) seed(acc, cur, blk);   // a tile is seeded right where it starts
+            if constexpr (T16) {
+                // norms two steps ahead: tile 1 of this block; tile 0 of the next block (next ring
+                // slot after the slot's last block: confirmed by this interval's barrier)
+                if constexpr (b == 6) seed16(cur, blk, I1c{});
+                if constexpr (b == 14) seed16(blk + 1 < BPS ? cur : nxt, (blk + 1) % BPS, I0c{});
+            } else if constexpr (b == 0) seed(acc, cur, blk);   // a tile is seeded right where it starts
             // (LAG 1, very first interval: its first LAGOFF steps chew on a not-yet-written ring
             //  slot; that accumulator is discarded below and re-seeded at the next tile)
-            mma_all(acc, fr[t % RING], std::integral_constant<int, b>{});
-            if constexpr (b == SPB - 1) {                // the tile's epilogue right at its end
-                if constexpr (u < 0) {
-                    if (!first) epilogue(acc, blk0_global - 1);
-                } else {
-                    epilogue(acc, blk0_global + blk);
+            if constexpr (T16) {
+                t16_step(acc, fr[t % RING], blk0_global + blk, std::integral_constant<int, b>{});
+            } else {
+                mma_all(acc, fr[t % RING], std::integral_constant<int, b>{});
+                if constexpr (b == SPB - 1) {                // the tile's epilogue right at its end
+                    if constexpr (u < 0) {
+                        if (!first) epilogue(acc, blk0_global - 1);
+                    } else {
+                        epilogue(acc, blk0_global + blk);
+                    }
                 }
             }
 #ifndef NNS_F_NOSCHED
@@ -658,6 +692,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     issue(1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(F_PPW + 1) : "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (T16) seed16(ring(0), 0, I0c{});   // the first block's tile-0 norms
     // (LAG 1 reads ring slot -1 here: garbage in, discarded — see the interval)
     static_for<PF>([&](auto t) __attribute__((always_inline)) {
         constexpr int tt = decltype(t)::value;
@@ -671,11 +706,27 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             // everyone's share of slot s+1 has landed; everyone is done with slot s-2
             __builtin_amdgcn_s_barrier();
         }
-        if (!half) interval(I0{}, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
-        else if (lag) interval(I1{}, I1{}, s, ring(s), ring(s - 1), ring(s + 1));
-        else interval(I0{}, I1{}, s, ring(s), ring(s - 1), ring(s + 1));
+        if constexpr (OP::kLag) {
+            if (!half) interval(I0{}, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
+            else if (lag) interval(I1{}, I1{}, s, ring(s), ring(s - 1), ring(s + 1));
+            else interval(I0{}, I1{}, s, ring(s), ring(s - 1), ring(s + 1));
+        } else {   // lock-step partners; only the DMA issue steps differ
+            if (!half) interval(I0{}, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
+            else interval(I0{}, I1{}, s, ring(s), ring(s - 1), ring(s + 1));
+        }
     }
-    if (lag) {   // the lagging half block of the last slot; its first PF fragments are in the ring
+    if constexpr (T16) {   // ref tile 1 of the last block is still to be retired
+        OP::mma16_tail_fence(acc);
+        if constexpr ((kAblate & 2) == 0) {
+            static_for<4>([&](auto qc) __attribute__((always_inline)) {
+                const f32x4 &o = acc.template at<1, decltype(qc)::value>();
+                tmh[decltype(qc)::value] = fminf(fminf(fminf(o[0], o[1]), o[2]), o[3]);
+            });
+            t16_masks();
+            t16_test(acc, (slot0 + ns) * BPS - 1, std::integral_constant<int, 1>{});
+        }
+    }
+    if constexpr (OP::kLag) if (lag) {   // the lagging half block of the last slot; its first PF fragments are in the ring
         const char *lastp = ring(ns - 1);
         static_for<LAGOFF>([&](auto tc_) __attribute__((always_inline)) {
             constexpr int t = decltype(tc_)::value;
