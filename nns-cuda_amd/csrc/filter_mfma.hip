@@ -776,7 +776,7 @@ __global__ __launch_bounds__(64) void mfma_selftest_kernel(int kt, int bf16, con
         }
     } else {
         // bf16 == 2: the same 32x32 product as four 16x16 tiles of v_mfma_f32_16x16x32_bf16, with
-        // the operand / result lane mapping the filter's OpBF16 and K2's order 1 / 2 images assume
+        // the operand / result lane mapping the filter's OpBF16 and K2's order 1 image assume
         const int c = lane & 15, g = lane >> 4;
         for (int rt = 0; rt < 2; ++rt)
             for (int qt = 0; qt < 2; ++qt) {

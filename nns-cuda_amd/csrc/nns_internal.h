@@ -188,8 +188,7 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts,
 
 // bf16 points (raw uint16 bits) -> bf16 tile image [blk][16][64 lanes][8 bf16], value * scale
 // (scale = 1 or -2, exact), fp32 norms of the UNcentred points, max-|v| word
-// order: 0 = 32x32x16 operands; 16x16x32 operands: 1 = refs (fragment 2 ks + tile), 2 = queries
-// (fragment 8 tile + ks)
+// order: 0 = 32x32x16 operands, 1 = 16x16x32 operands (fragment 8 * tile + k-step)
 int launch_prep_image_bf16(int order, int k, int npts, int npts_pad, const uint16_t *pts, float scale,
                            float pad_norm, void *img, float *norms, unsigned *max_norm_bits,
                            unsigned *maxabs_bits, hipStream_t st);

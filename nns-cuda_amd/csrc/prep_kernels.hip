@@ -280,10 +280,10 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, c
 // i — one v_mfma_f32_32x32x16_bf16 operand per ds_read_b128.  No centring (a centred bf16
 // value would need a second rounding); the scale (-2 for refs) is exact in bf16.
 //
-// order 1 / 2 (v_mfma_f32_16x16x32_bf16 operands): a fragment is one 16-point tile t x one k-step
-// ks of 32 dims; lane l holds dims 32 ks + 8 (l >> 4) .. + 7 of point 16 t + (l & 15).  Refs
-// (order 1) store fragment 2 ks + t (the filter alternates the two ref tiles), queries (order 2)
-// fragment 8 t + ks (a wave keeps all k-steps of its four query tiles in registers).
+// order 1 (v_mfma_f32_16x16x32_bf16 operands, the product): a fragment is one 16-point tile t x
+// one k-step ks of 32 dims; lane l holds dims 32 ks + 8 (l >> 4) .. + 7 of point 16 t + (l & 15);
+// the block stores fragment 8 t + ks (the filter walks a ref tile's 8 k-steps in a row; a wave
+// keeps all k-steps of its four query tiles in registers).  order 0: the 32x32x16 layout above.
 __global__ __launch_bounds__(256) void image_bf16_kernel(int order, int k, int npts, const uint16_t *__restrict__ pts,
                                                          float scale, float pad_norm,
                                                          uint16_t *__restrict__ img, float *__restrict__ norms,
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void image_bf16_kernel(int order, int k, int n
             i = lane & 31;
             d0 = 16 * s + 8 * (lane >> 5);
         } else {
-            const int t = order == 1 ? (s & 1) : (s >> 3), ks = order == 1 ? (s >> 1) : (s & 7);
+            const int t = s >> 3, ks = s & 7;
             i = 16 * t + (lane & 15);
             d0 = 32 * ks + 8 * (lane >> 4);
         }
