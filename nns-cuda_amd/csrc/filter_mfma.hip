@@ -521,7 +521,11 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
                 constexpr int st = decltype(st_c)::value;
                 const float tm = tile_min(acc, st_c);
+#ifdef NNS_F_NOEXPECT
                 if (__builtin_amdgcn_ballot_w64(tm <= thr[st]) != 0ull)   // rare: ~ln(n) tiles per lane
+#else
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(tm <= thr[st]) != 0ull, 0))   // rare: ~ln(n) tiles per lane
+#endif
                     record_all(acc, blk_global, st_c);
             });
         }
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     auto t16_test = [&](typename OP::Acc &acc, int oblk, auto ot_c) __attribute__((always_inline)) {
         if constexpr (T16) {
             constexpr int ot = decltype(ot_c)::value;
-            if ((hm[0] | hm[1] | hm[2] | hm[3]) != 0ull) {
+            if (__builtin_expect((hm[0] | hm[1] | hm[2] | hm[3]) != 0ull, 0)) {   // cold: laid out off the MFMA stream
                 const int jbase = oblk * 32 + 16 * ot + 4 * (lane >> 4);
                 static_for<4>([&](auto st_c) __attribute__((always_inline)) {
                     constexpr int st = decltype(st_c)::value;
