@@ -209,11 +209,15 @@ struct OpBF16 {
                      : "+v"(acc)
                      : "v"(__builtin_bit_cast(f32x4, a)), "v"(__builtin_bit_cast(f32x4, b)));
     }
-    // first MFMA of a tile: srcC = the refs' norms (three-address form, dst must not overlap srcC)
+    // First MFMA of a tile: srcC = the refs' norms (three-address form).  The accumulator is an
+    // in/out operand although its old value is not read: that pins every tile to ONE register
+    // tuple for the whole kernel.  As a fresh output the allocator may give it another tuple and
+    // reconcile at the loop back-edge with v_mov copies of the accumulators right behind the
+    // interval's last MFMAs — a read hazard (caught by tools/check_mfma_hazards.py).
     __device__ static __forceinline__ void mma16_seed(const float4 &a, const float4 &b, f32x4 &acc, const f32x4 &c)
     {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
-                     : "=&v"(acc)
+                     : "+v"(acc)
                      : "v"(__builtin_bit_cast(f32x4, a)), "v"(__builtin_bit_cast(f32x4, b)), "v"(c));
     }
     // VALU may read an accumulator 8 wait states after the MFMA that wrote it issued (what hipcc
@@ -224,7 +228,7 @@ struct OpBF16 {
     // the reads are ordered behind it.
     __device__ static __forceinline__ void mma16_tail_fence(AccSet16 &c)
     {
-        asm volatile("s_nop 7\n\ts_nop 1" : "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13));
+        asm volatile("s_nop 7" : "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13));
     }
 };
 
@@ -648,11 +652,23 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             // for the two SIMD partners (an LDS-DMA issue stalls the issuing wave ~100 cycles;
             // past the end of the shard it reads the image's padding)
             if constexpr ((kAblate & 16) == 0) {
+#ifdef NNS_F_DMA_SAMEPHASE
+                constexpr int d0 = 2;
+#else
                 constexpr int d0 = DPH == 0 ? 2 : 16;
+#endif
+#ifdef NNS_F_DMA_SP
+                constexpr int sp = NNS_F_DMA_SP;
+#else
                 constexpr int sp = (F_PPW + 1) * 2 <= 14 ? 2 : 1;   // steps between pieces
+#endif
                 static_assert(d0 + sp * (F_PPW + 1) <= 32, "DMA pieces must fit the interval");
+#ifdef NNS_F_DMA_BURST
+                if constexpr (t == d0) issue(s + 2);
+#else
                 if constexpr (t >= d0 && t < d0 + sp * (F_PPW + 1) && (t - d0) % sp == 0)
                     issue_piece(s + 2, (t - d0) / sp);
+#endif
             }
             if constexpr (T16) {
                 // norms two steps ahead: tile 1 of this block; tile 0 of the next block (next ring
@@ -714,9 +730,15 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             if (!half) interval(I0{}, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
             else if (lag) interval(I1{}, I1{}, s, ring(s), ring(s - 1), ring(s + 1));
             else interval(I0{}, I1{}, s, ring(s), ring(s - 1), ring(s + 1));
-        } else {   // lock-step partners; only the DMA issue steps differ
-            if (!half) interval(I0{}, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
-            else interval(I0{}, I1{}, s, ring(s), ring(s - 1), ring(s + 1));
+        } else {
+            // lock-step partners, one code path (staggering only their DMA issue steps, or packing /
+            // spreading the pieces differently, measured +-0.5 % on C5)
+            interval(I0{}, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
+            // The interval ends on the MFMAs that finish ref tile 1, which is retired in the NEXT
+            // interval: hipcc is free to split / copy those accumulators at the loop back-edge
+            // (it did: v_mov of single elements right behind the MFMAs = stale reads).  Whatever it
+            // does with them now happens behind the 8 wait states their readers need.
+            if constexpr (T16) OP::mma16_tail_fence(acc);
         }
     }
     if constexpr (T16) {   // ref tile 1 of the last block is still to be retired

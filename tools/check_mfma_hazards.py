@@ -15,10 +15,9 @@ generated code after every build:
 
 WAIT = 8 for the 4-pass 16x16x32 (what hipcc itself inserts behind the builtin: s_nop 7), 12 for
 the 32x32x16 / 32x32x2 forms (s_nop 11).  s_nop N counts N + 1 wait states, every other
-instruction 1 (a lower bound on the time it takes).  Straight-line scan per kernel; labels do
-not reset it (fall-through is the worst case), an unconditional branch does, conditional branches
-are not followed (their targets start with no MFMA pending: optimistic, so the kernel source keeps
-its readers a full step behind the writers on every path).
+instruction 1 (a lower bound on the time it takes).  The fall-through path is scanned from the
+top of each kernel; every branch taken while results are pending (conditional, or the loop's
+back-edge) is followed into its target for as long as they stay pending.
 
 usage: check_mfma_hazards.py [file.s]      (without a file: compiles filter_mfma.hip to ISA)
 exit status 0 = clean.
@@ -66,47 +65,84 @@ def operands(line: str):
 
 
 def check_kernel(name: str, lines) -> list:
-    problems = []
-    pending = []   # [dst set, remaining wait states, mnemonic, line number, exact dst token]
+    """lines: [(line number, text)].  Scans the fall-through path from the top and, from every
+    conditional branch taken while MFMA results are still pending, the target's first
+    instructions with that pending state (pending entries expire within <= 12 wait states, so
+    these side scans are short)."""
+    insts = []      # (line number, mnemonic, operand tokens, raw)
+    label_at = {}   # label -> index into insts of the first instruction behind it
     for ln, raw in lines:
         s = raw.strip()
-        if not s or s.startswith((";", ".", "//")) or s.endswith(":"):
+        if not s or s.startswith((";", "//")):
+            continue
+        m = re.match(r"^([.\w$]+):", s)
+        if m:
+            label_at[m.group(1)] = len(insts)
+            continue
+        if s.startswith("."):
             continue
         mn, ops = operands(s)
-        if not mn or mn.startswith("."):
-            continue
-        if mn in ("s_branch", "s_setpc_b64", "s_endpgm"):   # control leaves: what follows is not reached from here
-            pending = []
-            continue
-        if mn == "s_nop":
-            n = int(ops[0], 0) + 1 if ops else 1
-            for p in pending:
-                p[1] -= n
-            pending = [p for p in pending if p[1] > 0]
-            continue
-        touched = set()
-        for o in ops:
-            touched |= vregs(o)
-        is_mfma = mn.startswith("v_mfma")
-        for p in pending:
-            if not (touched & p[0]):
+        if mn:
+            insts.append((ln, mn, ops, s))
+
+    problems = set()
+
+    def scan(start: int, pending: list, follow: bool):
+        side = []
+        i = start
+        while i < len(insts):
+            ln, mn, ops, s = insts[i]
+            i += 1
+            if mn in ("s_branch", "s_setpc_b64", "s_endpgm"):
+                if mn == "s_branch" and pending and ops and ops[0] in label_at:
+                    side.append((label_at[ops[0]], [list(p) for p in pending]))
+                pending = []
+                if not follow:
+                    break
                 continue
+            if mn.startswith("s_cbranch") and pending and ops and ops[-1] in label_at:
+                side.append((label_at[ops[-1]], [list(p) for p in pending]))
+            if mn == "s_nop":
+                n = int(ops[0], 0) + 1 if ops else 1
+                for p in pending:
+                    p[1] -= n
+                pending = [p for p in pending if p[1] > 0]
+                if not follow and not pending:
+                    break
+                continue
+            touched = set()
+            for o in ops:
+                touched |= vregs(o)
+            is_mfma = mn.startswith("v_mfma")
+            for p in pending:
+                if not (touched & p[0]):
+                    continue
+                if is_mfma:
+                    # allowed: accumulate in place on exactly the same tuple (dst == srcC == pending dst)
+                    ab = vregs(ops[1]) | vregs(ops[2])
+                    same_c = ops[3] == p[4] and ops[0] == p[4]
+                    if (ab & p[0]) or not same_c:
+                        problems.add(f"{name}: line {ln}: '{s}' uses {p[4]} of {p[2]} (line {p[3]}) "
+                                     f"{WAITS.get(p[2], 12) - p[1]} wait states after it")
+                else:
+                    problems.add(f"{name}: line {ln}: '{s}' touches {p[4]} written by {p[2]} (line {p[3]}) "
+                                 f"only {WAITS.get(p[2], 12) - p[1]} wait states earlier")
+            for p in pending:
+                p[1] -= 1
+            pending = [p for p in pending if p[1] > 0]
             if is_mfma:
-                # allowed: accumulate in place on exactly the same tuple (dst == srcC == pending dst)
-                ab = vregs(ops[1]) | vregs(ops[2])
-                same_c = ops[3] == p[4] and ops[0] == p[4]
-                if (ab & p[0]) or not same_c:
-                    problems.append(f"{name}: line {ln}: '{s}' uses {p[4]} of {p[2]} (line {p[3]}) "
-                                    f"{WAITS.get(p[2], 12) - p[1]} wait states after it")
-            else:
-                problems.append(f"{name}: line {ln}: '{s}' touches {p[4]} written by {p[2]} (line {p[3]}) "
-                                f"only {WAITS.get(p[2], 12) - p[1]} wait states earlier")
-        for p in pending:
-            p[1] -= 1
-        pending = [p for p in pending if p[1] > 0]
-        if is_mfma:
-            pending.append([vregs(ops[0]), WAITS.get(mn, 12), mn, ln, ops[0]])
-    return problems
+                pending.append([vregs(ops[0]), WAITS.get(mn, 12), mn, ln, ops[0]])
+            if not follow and not pending:
+                break
+        return side
+
+    todo = scan(0, [], True)
+    seen = 0
+    while todo and seen < 100000:
+        start, pend = todo.pop()
+        seen += 1
+        todo += scan(start, pend, False)
+    return sorted(problems)
 
 
 def main() -> int:
