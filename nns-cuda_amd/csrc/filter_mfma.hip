@@ -194,7 +194,7 @@ struct OpBF16 {
     static constexpr int kQB = 2;             // 64 queries per wave = 4 query tiles
     static constexpr int kNW = NNS_F_NW_BF16;
 #ifndef NNS_F_PF_BF16
-#define NNS_F_PF_BF16 1   // (2 fits the 32x32x16 variant; here it spills three query fragments)
+#define NNS_F_PF_BF16 2
 #endif
     static constexpr int kPrefetch = NNS_F_PF_BF16;
     // Inline asm, accumulating IN PLACE: through the builtin hipcc picks the three-address form

@@ -21,7 +21,10 @@ def main():
     sums = defaultdict(float)
     counts = defaultdict(int)
     for d in sys.argv[4:]:
-        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        # gpurun merges results into the same local directory call after call: only the newest
+        # collection of each pass counts
+        found = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+        for path in found[-1:]:
             with open(path, newline="") as f:
                 for row in csv.DictReader(f):
                     if needle not in row.get("Kernel_Name", ""):
