@@ -528,3 +528,63 @@ def test_workspace_pool_reuse_and_trim(pkg, orc):
     assert pkg.trim() == 0
     for (q, r), w in zip(data, want):
         assert np.array_equal(pkg.search(q, r), w)
+
+
+def test_c5_headline_shape_properties(pkg, orc):
+    """BASELINE C5 (131072 x 2097152 x 256 bf16 points) at full size through the 16x16x32 bf16
+    filter: planted exact matches, sampled queries against the oracle (V0 arithmetic on the bf16
+    values) over ALL refs, distances bit-equal to V0's pair arithmetic, 2-shard invariance of the
+    keys.  bf16 values collide far more often than fp32 ones, so ties are exercised for real."""
+    m, n, k = 131072, 2097152, 256
+    q = torch.empty((m, k), dtype=torch.float32, device="cuda")
+    pkg.fill_uniform(q, 1000, 0)
+    qb = q.to(torch.bfloat16)
+    del q
+    r = torch.empty((n, k), dtype=torch.float32, device="cuda")
+    pkg.fill_uniform(r, 1000, m * k)
+    rb = r.to(torch.bfloat16)
+    del r
+    torch.cuda.empty_cache()
+    planted_q = torch.arange(0, 512, device="cuda") * 251
+    planted_r = (torch.arange(0, 512, device="cuda") * 4093 + 29) % n
+    qb[planted_q] = rb[planted_r]
+    ix = pkg.Index(rb)
+    keys = ix.search_keys(qb)
+    idx, dist = pkg.keys_unpack(keys, return_distances=True)
+    torch.cuda.synchronize()
+    st = ix.stats()
+    assert st["path"] == 2 and st["k_tile"] == 256 and st["nonfinite"] == 0, st
+    assert st["ambiguous"] < m // 20, st
+    idx_h, dist_h = idx.cpu().numpy(), dist.cpu().numpy()
+    pq = planted_q.cpu().numpy()
+    assert (dist_h[pq] == 0).all()
+    # a planted query's answer is the LOWEST ref index at distance 0 (an identical bf16 row earlier
+    # in the cloud would be V0's answer too); with 256 random dims that is the planted row itself
+    assert np.array_equal(idx_h[pq], planted_r.cpu().numpy().astype(np.int32))
+    assert idx_h.min() >= 0 and idx_h.max() < n
+    # sampled queries against the oracle over ALL refs (bf16 bits widened exactly to fp32)
+    rh = rb.view(torch.int16).cpu().numpy().view(np.uint16)
+    rw = (rh.astype(np.uint32) << 16).view(np.float32)
+    del rh
+    sel = np.random.default_rng(5).choice(m, 24, replace=False)
+    qsel = qb[torch.from_numpy(sel).cuda()].view(torch.int16).cpu().numpy().view(np.uint16)
+    qw = (qsel.astype(np.uint32) << 16).view(np.float32)
+    want_idx, want_dist = orc.v0_search(qw, rw, threads=16)
+    assert np.array_equal(idx_h[sel], want_idx)
+    assert np.array_equal(_bits(dist_h[sel]), _bits(want_dist))
+    for i in range(0, m, 8191):
+        qi = (qb[i].view(torch.int16).cpu().numpy().view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+        assert _bits(dist_h[i:i + 1])[0] == orc.pair_distance(qi, rw[idx_h[i]]).view(np.uint32)
+    del rw
+    ix.close()
+    half = n // 2
+    k0 = pkg.Index(rb[:half], index_base=0)
+    a = k0.search_keys(qb).clone()
+    torch.cuda.synchronize()
+    k0.close()
+    k1 = pkg.Index(rb[half:], index_base=half)
+    b = k1.search_keys(qb)
+    pkg.keys_min(a, b)
+    torch.cuda.synchronize()
+    k1.close()
+    assert torch.equal(a, keys)
