@@ -86,7 +86,9 @@ typedef uint64_t nns_key;
 /* opaque handle: one device-resident, prepared shard of reference points */
 typedef struct nns_index nns_index;
 
-/* per-search statistics (NNS_PROFILE adds the *_ms fields) */
+/* per-search statistics.  NNS_PROFILE adds the *_ms fields (HIP events on the caller's stream):
+ * averages over the searches since the previous nns_index_stats call (the last 32 at most), so
+ * a caller can run many refresh + search steps back to back and read them once. */
 typedef struct nns_stats {
     int path;              /* NNS_PATH_EXACT or NNS_PATH_MFMA actually taken */
     int k_tile;            /* K of the MFMA tile (k padded up), 0 on the exact path */
@@ -99,7 +101,7 @@ typedef struct nns_stats {
     float finalize_ms;     /* K5 merge + exact distance of winners */
     float rerank_ms;       /* exact scan of ambiguous queries */
     float exact_ms;        /* exact path kernels (K1) */
-    float total_ms;        /* all device work of the last search */
+    float total_ms;        /* all device work of a search */
 } nns_stats;
 
 /* ---- whole-call drop-ins (host pointers; alloc + H2D + kernels + D2H) ------ */

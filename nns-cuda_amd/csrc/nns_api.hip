@@ -35,6 +35,7 @@ static const size_t F_IMG_ROW_BYTES = 512;
 static const int kTinyM = 64;
 
 enum { EV_BEGIN = 0, EV_QPREP, EV_FILTER, EV_FINAL, EV_RERANK, EV_END, EV_R0, EV_R1, EV_COUNT };
+static const int kEvRing = 32;
 
 struct nns_index {
     int device = 0;
@@ -67,7 +68,14 @@ struct nns_index {
     nns_key *exact_ws = nullptr;
     size_t exact_ws_keys = 0;
 
-    hipEvent_t ev[EV_COUNT] = {};
+    // NNS_PROFILE: a ring of event sets, one per search (refresh + search = one step), so that a
+    // caller can time many steps back to back and read the averages once, without a device
+    // synchronisation inside every step
+    hipEvent_t evr[kEvRing][EV_COUNT] = {};
+    bool ev_refreshed[kEvRing] = {};   // set holds a K2-on-refs interval
+    int ev_path[kEvRing] = {};         // path of the set's search
+    int ev_slot = 0;                   // set the next refresh / search records into
+    int ev_count = 0;                  // searches recorded since the last nns_index_stats
     bool ev_valid = false;
     bool searched = false;
     int last_m = 0;
@@ -151,7 +159,8 @@ int nns_index_destroy(nns_index *ix)
     pool_free(ix->amb_list);
     pool_free(ix->exact_ws);
     if (ix->ev_valid)
-        for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ix->ev[i]);
+        for (int r = 0; r < kEvRing; ++r)
+            for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ix->evr[r][i]);
     delete ix;
     return NNS_OK;
 }
@@ -199,7 +208,8 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
     do {
         if (ix->profile) {
             bool ok = true;
-            for (int i = 0; i < EV_COUNT; ++i) ok = ok && hipEventCreate(&ix->ev[i]) == hipSuccess;
+            for (int r = 0; r < kEvRing; ++r)
+                for (int i = 0; i < EV_COUNT; ++i) ok = ok && hipEventCreate(&ix->evr[r][i]) == hipSuccess;
             if (!ok) {
                 set_error("hipEventCreate failed");
                 rc = NNS_ERR_HIP;
@@ -222,9 +232,12 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
                 rc = NNS_ERR_NOMEM;
                 break;
             }
-            if (ix->profile) (void)hipEventRecord(ix->ev[EV_R0], st);
+            if (ix->profile) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_R0], st);
             if ((rc = prep_refs(ix, st)) != NNS_OK) break;
-            if (ix->profile) (void)hipEventRecord(ix->ev[EV_R1], st);
+            if (ix->profile) {
+                (void)hipEventRecord(ix->evr[ix->ev_slot][EV_R1], st);
+                ix->ev_refreshed[ix->ev_slot] = true;
+            }
             // index build is synchronous: learn whether the refs void the error bound
             DevScalars h{};
             if (hipMemcpyAsync(&h, ix->scal, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -262,9 +275,12 @@ int nns_index_refresh(nns_index *ix, void *stream)
     NNS_TRY(ensure_device_ok(ix->device));
     if (ix->path != NNS_PATH_MFMA) return NNS_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (ix->profile) (void)hipEventRecord(ix->ev[EV_R0], st);
+    if (ix->profile) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_R0], st);
     NNS_TRY(prep_refs(ix, st));
-    if (ix->profile) (void)hipEventRecord(ix->ev[EV_R1], st);
+    if (ix->profile) {
+        (void)hipEventRecord(ix->evr[ix->ev_slot][EV_R1], st);
+        ix->ev_refreshed[ix->ev_slot] = true;
+    }
     return NNS_OK;
 }
 
@@ -310,6 +326,16 @@ static int ensure_query_ws(nns_index *ix, int m)
     return NNS_OK;
 }
 
+// a search has recorded its events into the current set: close it and move on to the next one
+static void profile_advance(nns_index *ix, int path)
+{
+    if (!ix->profile) return;
+    ix->ev_path[ix->ev_slot] = path;
+    ix->ev_slot = (ix->ev_slot + 1) % kEvRing;
+    ix->ev_refreshed[ix->ev_slot] = false;
+    if (ix->ev_count < kEvRing) ++ix->ev_count;
+}
+
 static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, nns_key *keys_dev, void *stream)
 {
     if (ix && ix->bf16 != bf16) {
@@ -329,7 +355,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
     // is then HBM-bound and the exact lane-per-ref kernel is the faster path (AUTO only).
     const bool tiny = (ix->flags & NNS_PATH_MASK) == NNS_PATH_AUTO && m < kTinyM;
     if (ix->path != NNS_PATH_MFMA || ix->refs_bad || tiny) {
-        if (prof) (void)hipEventRecord(ix->ev[EV_BEGIN], st);
+        if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_BEGIN], st);
         if (bf16)
             NNS_TRY(launch_exact_search_bf16(ix->k, m, ix->n, (const uint16_t *)q_dev, (const uint16_t *)ix->r_dev,
                                              ix->base, keys_dev, st));
@@ -347,15 +373,16 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
             NNS_TRY(launch_exact_search(ix->k, m, ix->n, (const float *)q_dev, (const float *)ix->r_dev, ix->base,
                                         keys_dev, ix->exact_ws, ix->exact_ws_keys, st));
         }
-        if (prof) (void)hipEventRecord(ix->ev[EV_END], st);
+        if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_END], st);
         ix->last_path = NNS_PATH_EXACT;
         ix->searched = true;
+        profile_advance(ix, NNS_PATH_EXACT);
         return NNS_OK;
     }
 
     NNS_TRY(ensure_query_ws(ix, m));
     const FilterGeom &g = ix->geom;
-    if (prof) (void)hipEventRecord(ix->ev[EV_BEGIN], st);
+    if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_BEGIN], st);
     // reset the per-search scalars (q max-abs, ambiguous count); keep the ref-side ones
     NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned), st));
     NNS_HIP(hipMemsetAsync(&ix->scal->amb_count, 0, sizeof(int), st));
@@ -365,26 +392,27 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
     else
         NNS_TRY(launch_prep_image(ix->k, g.kt, m, g.m_pad, (const float *)q_dev, ix->mean, 1.0f, 0.0f,
                                   (float *)ix->qimg, ix->qnorm, nullptr, &ix->scal->q_maxabs_bits, st));
-    if (prof) (void)hipEventRecord(ix->ev[EV_QPREP], st);
+    if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_QPREP], st);
     NNS_TRY(launch_filter(g, ix->qimg, ix->rimg, ix->rnorm, ix->qnorm, ix->scal, ix->lists, ix->counts, st));
-    if (prof) (void)hipEventRecord(ix->ev[EV_FILTER], st);
+    if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_FILTER], st);
     // tuning diagnostic for ablated filter builds (-DNNS_FILTER_ABLATE: empty candidate lists would
     // send every query to the exact scan): stop after the filter; the keys are NOT results
     static const bool filter_only = getenv("NNS_DIAG_FILTER_ONLY") != nullptr;
     if (filter_only) {
         NNS_TRY(launch_keys_fill(keys_dev, m, NNS_KEY_NONE, st));
         if (prof) {
-            (void)hipEventRecord(ix->ev[EV_FINAL], st);
-            (void)hipEventRecord(ix->ev[EV_RERANK], st);
-            (void)hipEventRecord(ix->ev[EV_END], st);
+            (void)hipEventRecord(ix->evr[ix->ev_slot][EV_FINAL], st);
+            (void)hipEventRecord(ix->evr[ix->ev_slot][EV_RERANK], st);
+            (void)hipEventRecord(ix->evr[ix->ev_slot][EV_END], st);
         }
         ix->last_path = NNS_PATH_MFMA;
         ix->searched = true;
+        profile_advance(ix, NNS_PATH_MFMA);
         return NNS_OK;
     }
     NNS_TRY(launch_finalize(g, ix->k, m, ix->n, q_dev, ix->r_dev, ix->lists, ix->counts, ix->qnorm,
                             ix->scal, ix->base, keys_dev, ix->amb_list, st));
-    if (prof) (void)hipEventRecord(ix->ev[EV_FINAL], st);
+    if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_FINAL], st);
     if (bf16)
         NNS_TRY(launch_exact_listed_bf16(ix->k, ix->n, (const uint16_t *)q_dev, (const uint16_t *)ix->r_dev,
                                          ix->amb_list, &ix->scal->amb_count, m, ix->base, keys_dev, st));
@@ -392,11 +420,12 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
         NNS_TRY(launch_exact_listed(ix->k, ix->n, (const float *)q_dev, (const float *)ix->r_dev, ix->amb_list,
                                     &ix->scal->amb_count, m, ix->base, keys_dev, st));
     if (prof) {
-        (void)hipEventRecord(ix->ev[EV_RERANK], st);
-        (void)hipEventRecord(ix->ev[EV_END], st);
+        (void)hipEventRecord(ix->evr[ix->ev_slot][EV_RERANK], st);
+        (void)hipEventRecord(ix->evr[ix->ev_slot][EV_END], st);
     }
     ix->last_path = NNS_PATH_MFMA;
     ix->searched = true;
+    profile_advance(ix, NNS_PATH_MFMA);
     return NNS_OK;
 }
 
@@ -428,20 +457,49 @@ int nns_index_stats(nns_index *ix, nns_stats *out)
     }
     if (ix->profile && ix->ev_valid) {
         NNS_HIP(hipDeviceSynchronize());
-        float ms = 0;
-        if (ix->path == NNS_PATH_MFMA && hipEventElapsedTime(&ms, ix->ev[EV_R0], ix->ev[EV_R1]) == hipSuccess)
-            out->prep_refs_ms = ms;
-        if (ix->searched) {
-            if (ix->last_path == NNS_PATH_MFMA) {
-                if (hipEventElapsedTime(&ms, ix->ev[EV_BEGIN], ix->ev[EV_QPREP]) == hipSuccess) out->prep_queries_ms = ms;
-                if (hipEventElapsedTime(&ms, ix->ev[EV_QPREP], ix->ev[EV_FILTER]) == hipSuccess) out->filter_ms = ms;
-                if (hipEventElapsedTime(&ms, ix->ev[EV_FILTER], ix->ev[EV_FINAL]) == hipSuccess) out->finalize_ms = ms;
-                if (hipEventElapsedTime(&ms, ix->ev[EV_FINAL], ix->ev[EV_RERANK]) == hipSuccess) out->rerank_ms = ms;
-            } else {
-                if (hipEventElapsedTime(&ms, ix->ev[EV_BEGIN], ix->ev[EV_END]) == hipSuccess) out->exact_ms = ms;
+        // averages over the searches recorded since the previous call (the last kEvRing at most)
+        const int cnt = ix->ev_count;
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // refs, qprep, filter, final, rerank, exact, total
+        int n_refs = 0, n_mfma = 0, n_exact = 0;
+        auto span = [&](int set, int a, int b, double *dst) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ix->evr[set][a], ix->evr[set][b]) == hipSuccess) *dst += ms;
+        };
+        if (cnt == 0) {
+            // nothing searched since the last call: the index build / a refresh alone
+            if (ix->ev_refreshed[ix->ev_slot]) {
+                span(ix->ev_slot, EV_R0, EV_R1, &acc[0]);
+                n_refs = 1;
             }
-            if (hipEventElapsedTime(&ms, ix->ev[EV_BEGIN], ix->ev[EV_END]) == hipSuccess) out->total_ms = ms;
         }
+        for (int j = 0; j < cnt; ++j) {
+            const int set = (ix->ev_slot - 1 - j + 2 * kEvRing) % kEvRing;
+            if (ix->ev_refreshed[set]) {
+                span(set, EV_R0, EV_R1, &acc[0]);
+                ++n_refs;
+            }
+            if (ix->ev_path[set] == NNS_PATH_MFMA) {
+                span(set, EV_BEGIN, EV_QPREP, &acc[1]);
+                span(set, EV_QPREP, EV_FILTER, &acc[2]);
+                span(set, EV_FILTER, EV_FINAL, &acc[3]);
+                span(set, EV_FINAL, EV_RERANK, &acc[4]);
+                ++n_mfma;
+            } else {
+                span(set, EV_BEGIN, EV_END, &acc[5]);
+                ++n_exact;
+            }
+            span(set, EV_BEGIN, EV_END, &acc[6]);
+        }
+        if (n_refs) out->prep_refs_ms = (float)(acc[0] / n_refs);
+        if (n_mfma) {
+            out->prep_queries_ms = (float)(acc[1] / n_mfma);
+            out->filter_ms = (float)(acc[2] / n_mfma);
+            out->finalize_ms = (float)(acc[3] / n_mfma);
+            out->rerank_ms = (float)(acc[4] / n_mfma);
+        }
+        if (n_exact) out->exact_ms = (float)(acc[5] / n_exact);
+        if (cnt) out->total_ms = (float)(acc[6] / cnt);
+        ix->ev_count = 0;
         (void)hipGetLastError();
     }
     return NNS_OK;
