@@ -69,7 +69,11 @@ enum {
     NNS_PATH_MFMA = 2,   /* -2*Q*R^T MFMA filter + exact re-rank (k padded to the tile K) */
     NNS_PATH_MASK = 3,
     NNS_PROFILE = 16,    /* record HIP-event timings per stage (adds syncs at read-out) */
-    NNS_MULTI_VIRTUAL = 32 /* nns_search_f32_multi: allow more shards than GPUs (rehearsal) */
+    NNS_MULTI_VIRTUAL = 32, /* nns_search_f32_multi: allow more shards than GPUs (rehearsal) */
+    NNS_REFS_SOA = 64    /* the reference points are given dimension-major, r[t * n + j] (a dense [k][n]
+                          * array: the layout v4::mat_inv_kernel produces, core.cu:293-306, :327) instead
+                          * of r[j * k + t]; queries stay [m][k].  The library transposes once on the
+                          * device into a copy it owns.  Not accepted by nns_search_f32_multi. */
 };
 
 /*

@@ -44,6 +44,8 @@ struct nns_index {
     unsigned flags = 0;
     int path = NNS_PATH_EXACT;
     const void *r_dev = nullptr;   // fp32 [n][k] or bf16 bits [n][k]
+    const void *r_soa = nullptr;   // NNS_REFS_SOA: the caller's [k][n] array; r_dev is then r_own
+    void *r_own = nullptr;         // owned point-major copy of r_soa
     int bf16 = 0;
     bool profile = false;
     bool refs_bad = false;
@@ -147,6 +149,7 @@ int nns_index_destroy(nns_index *ix)
     // workspaces go back to the pool, not to hipFree (which would wait for the device itself):
     // make sure nothing still reads them
     (void)hipDeviceSynchronize();
+    pool_free(ix->r_own);
     pool_free(ix->rimg);
     pool_free(ix->rnorm);
     pool_free(ix->mean);
@@ -189,6 +192,22 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
     ix->flags = flags;
     ix->r_dev = r_dev;
     ix->bf16 = bf16;
+    if (flags & NNS_REFS_SOA) {
+        // dimension-major refs: one transpose into a point-major copy the index owns
+        const size_t esz = bf16 ? sizeof(uint16_t) : sizeof(float);
+        ix->r_soa = r_dev;
+        if (pool_alloc(&ix->r_own, (size_t)n * k * esz) != hipSuccess) {
+            set_error("nns_index_create: device allocation failed (point-major copy of %d x %d refs)", n, k);
+            delete ix;
+            return NNS_ERR_NOMEM;
+        }
+        const int trc = launch_soa_to_aos(k, n, r_dev, ix->r_own, (int)esz, st);
+        if (trc != NNS_OK) {
+            nns_index_destroy(ix);
+            return trc;
+        }
+        ix->r_dev = ix->r_own;
+    }
     ix->profile = (flags & NNS_PROFILE) != 0;
 
     const int kmax = bf16 ? 256 : 128;   // tile depth of the MFMA filter
@@ -273,8 +292,10 @@ int nns_index_refresh(nns_index *ix, void *stream)
 {
     if (!ix) return NNS_ERR_INVALID;
     NNS_TRY(ensure_device_ok(ix->device));
-    if (ix->path != NNS_PATH_MFMA) return NNS_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (ix->r_soa)   // the caller's dimension-major array may have changed
+        NNS_TRY(launch_soa_to_aos(ix->k, ix->n, ix->r_soa, ix->r_own, ix->bf16 ? 2 : 4, st));
+    if (ix->path != NNS_PATH_MFMA) return NNS_OK;
     if (ix->profile) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_R0], st);
     NNS_TRY(prep_refs(ix, st));
     if (ix->profile) {
@@ -561,7 +582,7 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
     if (num_shards > n) num_shards = n;   // the reference clamps GPUs to n (core.cu:771-772)
     if ((flags & NNS_PATH_MASK) == NNS_PATH_AUTO && m < kTinyM) flags |= NNS_PATH_EXACT;
 
-    char *q_d = nullptr, *r_d = nullptr;
+    char *q_d = nullptr, *r_d = nullptr, *r_t = nullptr;
     float *dist_d = nullptr;
     nns_key *keys = nullptr, *keys_tmp = nullptr;
     int *idx_d = nullptr;
@@ -584,6 +605,19 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             set_error("nns_search_f32: H2D copy failed: %s", hipGetErrorString(hipGetLastError()));
             rc = NNS_ERR_HIP;
             break;
+        }
+        if (flags & NNS_REFS_SOA) {
+            // dimension-major refs: transpose once on the device, then shard the point-major copy
+            if (pool_alloc(&r_t, rb) != hipSuccess) {
+                set_error("nns_search_f32: device allocation failed (point-major copy)");
+                rc = NNS_ERR_NOMEM;
+                break;
+            }
+            if ((rc = launch_soa_to_aos(k, n, r_d, r_t, (int)esz, st)) != NNS_OK) break;
+            char *tmp = r_d;
+            r_d = r_t;
+            r_t = tmp;
+            flags &= ~(unsigned)NNS_REFS_SOA;
         }
         // contiguous ceil(n / shards) ranges (reference split rule core.cu:781-791)
         const int per = divup(n, num_shards);
@@ -613,8 +647,10 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             rc = NNS_ERR_HIP;
         }
     } while (0);
+    (void)hipDeviceSynchronize();   // the blocks go back to the pool: nothing may still use them
     pool_free(q_d);
     pool_free(r_d);
+    pool_free(r_t);
     pool_free(keys);
     pool_free(keys_tmp);
     pool_free(idx_d);

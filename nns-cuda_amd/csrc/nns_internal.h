@@ -188,6 +188,9 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts,
 
 // bf16 points (raw uint16 bits) -> bf16 tile image [blk][16][64 lanes][8 bf16], value * scale
 // (scale = 1 or -2, exact), fp32 norms of the UNcentred points, max-|v| word
+// dimension-major [k][n] -> point-major [n][k] (the inverse of the reference's mat_inv_kernel,
+// core.cu:293-306); esz = 4 (fp32) or 2 (bf16 bits)
+int launch_soa_to_aos(int k, int n, const void *src, void *dst, int esz, hipStream_t st);
 // order: 0 = 32x32x16 operands, 1 = 16x16x32 operands (fragment 8 * tile + k-step)
 int launch_prep_image_bf16(int order, int k, int npts, int npts_pad, const uint16_t *pts, float scale,
                            float pad_norm, void *img, float *norms, unsigned *max_norm_bits,

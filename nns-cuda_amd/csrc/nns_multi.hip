@@ -104,6 +104,10 @@ extern "C" int nns_search_f32_multi(int k, int m, int n, const float *s_points, 
         set_error("nns_search_f32_multi: k, m, n must be > 0 and pointers non-null");
         return NNS_ERR_INVALID;
     }
+    if (flags & NNS_REFS_SOA) {
+        set_error("nns_search_f32_multi: NNS_REFS_SOA is not supported (shards are ranges of point-major refs)");
+        return NNS_ERR_UNSUPPORTED;
+    }
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) {
         set_error("no HIP device visible (the HIP path has no CPU fallback)");

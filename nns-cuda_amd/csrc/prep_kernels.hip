@@ -393,4 +393,37 @@ int launch_prep_image_bf16(int order, int k, int npts, int npts_pad, const uint1
     return NNS_OK;
 }
 
+// ---- SoA -> AoS (NNS_REFS_SOA) --------------------------------------------------------------
+// Tile = 32 dims x 64 points through LDS: reads are 64 consecutive points of one dimension row
+// (256 B / 128 B runs), writes 32 consecutive dims of one point (128 B / 64 B runs).  HBM-bound:
+// 2 * n * k * esz bytes.  (The reference's mat_inv_kernel, core.cu:293-306, goes the other way
+// with one thread per element and strided writes.)
+template <typename T>
+__global__ __launch_bounds__(256) void soa_to_aos_kernel(int k, int n, const T *__restrict__ src, T *__restrict__ dst)
+{
+    __shared__ T tile[32][64 + 2];
+    const int j0 = blockIdx.x * 64, t0 = blockIdx.y * 32;
+    for (int e = threadIdx.x; e < 32 * 64; e += 256) {
+        const int t = e >> 6, j = e & 63;
+        if (t0 + t < k && j0 + j < n) tile[t][j] = src[(size_t)(t0 + t) * n + j0 + j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+        const int j = e >> 5, t = e & 31;
+        if (t0 + t < k && j0 + j < n) dst[(size_t)(j0 + j) * k + t0 + t] = tile[t][j];
+    }
+}
+
+int launch_soa_to_aos(int k, int n, const void *src, void *dst, int esz, hipStream_t st)
+{
+    const dim3 grid(divup(n, 64), divup(k, 32));
+    if (esz == 4)
+        hipLaunchKernelGGL(soa_to_aos_kernel<float>, grid, dim3(256), 0, st, k, n, (const float *)src, (float *)dst);
+    else
+        hipLaunchKernelGGL(soa_to_aos_kernel<uint16_t>, grid, dim3(256), 0, st, k, n, (const uint16_t *)src,
+                           (uint16_t *)dst);
+    NNS_HIP(hipGetLastError());
+    return NNS_OK;
+}
+
 }  // namespace nns

@@ -26,7 +26,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NNS_LIB_PATH") or os.path.join(_HERE, "libnns_mi355x.so")   # override: A/B of builds
 
 NNS_OK = 0
-NNS_PATH_AUTO, NNS_PATH_EXACT, NNS_PATH_MFMA, NNS_PROFILE, NNS_MULTI_VIRTUAL = 0, 1, 2, 16, 32
+NNS_PATH_AUTO, NNS_PATH_EXACT, NNS_PATH_MFMA, NNS_PROFILE, NNS_MULTI_VIRTUAL, NNS_REFS_SOA = 0, 1, 2, 16, 32, 64
 NNS_KEY_NONE = 0x7F80000000000000
 
 _PATHS = {"auto": NNS_PATH_AUTO, "exact": NNS_PATH_EXACT, "mfma": NNS_PATH_MFMA}
@@ -160,23 +160,24 @@ def cudaCall(k: int, m: int, n: int, s_points, r_points) -> np.ndarray:
 
 
 def search(query_points, reference_points, *, return_distances: bool = False, shards: int = 1,
-           path: str = "auto", device: int = 0):
+           path: str = "auto", device: int = 0, refs_soa: bool = False):
     """``search(query_points, reference_points)`` — the entry point BASELINE.json names.
 
     Host arrays in, nearest-reference index per query out (and, optionally, V0's
     fp32 squared distance).  ``shards`` > 1 rehearses the multi-GPU ref split on one
-    device (contiguous ceil(n/shards) ranges merged with the packed-key min)."""
+    device (contiguous ceil(n/shards) ranges merged with the packed-key min).  ``refs_soa``:
+    reference_points is dimension-major [k][n] (NNS_REFS_SOA, the reference's V4 layout)."""
     q = _as_f32(query_points, "query_points")
     r = _as_f32(reference_points, "reference_points")
-    if q.shape[1] != r.shape[1]:
+    if q.shape[1] != (r.shape[0] if refs_soa else r.shape[1]):
         raise ValueError("query and reference dimensionality differ")
     m, k = q.shape
-    n = r.shape[0]
+    n = r.shape[1] if refs_soa else r.shape[0]
     idx = np.empty(m, dtype=np.int32)
     dist = np.empty(m, dtype=np.float32) if return_distances else None
     _check(lib.nns_search_f32_ex(k, m, n, q.ctypes.data, r.ctypes.data, idx.ctypes.data,
                                  dist.ctypes.data if dist is not None else None, shards,
-                                 _PATHS[path], device), "nns_search_f32_ex")
+                                 _PATHS[path] | (NNS_REFS_SOA if refs_soa else 0), device), "nns_search_f32_ex")
     return (idx, dist) if return_distances else idx
 
 
@@ -248,16 +249,18 @@ def fill_uniform(t, seed: int, offset: int = 0, stream=None) -> None:
 class Index:
     """One prepared, device-resident shard of reference points (nns_index)."""
 
-    def __init__(self, refs, *, index_base: int = 0, path: str = "auto", profile: bool = False, stream=None):
+    def __init__(self, refs, *, index_base: int = 0, path: str = "auto", profile: bool = False, stream=None,
+                 soa: bool = False):
+        """refs: [n][k] (or, with soa=True, dimension-major [k][n]: NNS_REFS_SOA) on a HIP device."""
         import torch
         if refs.dtype not in (torch.float32, torch.bfloat16) or refs.dim() != 2 or not refs.is_contiguous() \
                 or not refs.is_cuda:
             raise ValueError("refs must be a contiguous fp32 or bf16 [n][k] tensor on a HIP device")
         self.bf16 = refs.dtype == torch.bfloat16
         self.refs = refs  # keep alive: the index reads the original values
-        self.n, self.k = refs.shape
+        self.n, self.k = (refs.shape[1], refs.shape[0]) if soa else refs.shape
         self.device = refs.device.index or 0
-        flags = _PATHS[path] | (NNS_PROFILE if profile else 0)
+        flags = _PATHS[path] | (NNS_PROFILE if profile else 0) | (NNS_REFS_SOA if soa else 0)
         h = ctypes.c_void_p()
         create = lib.nns_index_create_bf16 if self.bf16 else lib.nns_index_create
         _check(create(ctypes.byref(h), self.device, self.k, self.n, refs.data_ptr(),

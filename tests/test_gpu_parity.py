@@ -588,3 +588,39 @@ def test_c5_headline_shape_properties(pkg, orc):
     torch.cuda.synchronize()
     k1.close()
     assert torch.equal(a, keys)
+
+
+@pytest.mark.parametrize("shape", [(300, 5001, 128), (1000, 70000, 16), (4096, 8192, 3), (65, 999, 37), (33, 257, 100)])
+def test_dimension_major_refs(pkg, orc, shape):
+    """NNS_REFS_SOA: refs handed over as a dense [k][n] array (what the reference's mat_inv_kernel
+    produces, core.cu:293-306) give the same indices and distance bits as the [n][k] array —
+    whole call (with shards) and resident index (fp32 and bf16), including a refresh after the
+    caller changed the array."""
+    m, n, k = shape
+    rng = np.random.default_rng(900 + k)
+    q = rng.random((m, k), dtype=np.float32)
+    r = rng.random((n, k), dtype=np.float32)
+    want_idx, want_dist = orc.v0_search(q, r, threads=8)
+    rt = np.ascontiguousarray(r.T)
+    for shards in (1, 3):
+        idx, dist = pkg.search(q, rt, return_distances=True, shards=shards, refs_soa=True)
+        assert np.array_equal(idx, want_idx) and np.array_equal(_bits(dist), _bits(want_dist))
+    qd = torch.from_numpy(q).cuda()
+    rtd = torch.from_numpy(rt).cuda()
+    ix = pkg.Index(rtd, soa=True, index_base=7)
+    idx, dist = ix.search(qd, return_distances=True)
+    assert np.array_equal(idx.cpu().numpy(), want_idx + 7) and np.array_equal(_bits(dist.cpu().numpy()), _bits(want_dist))
+    # the caller rewrites its array: refresh picks the new values up
+    r2 = rng.random((n, k), dtype=np.float32)
+    rtd.copy_(torch.from_numpy(np.ascontiguousarray(r2.T)))
+    ix.refresh()
+    idx2 = ix.search(qd)
+    assert np.array_equal(idx2.cpu().numpy(), orc.v0_search(q, r2, threads=8)[0] + 7)
+    ix.close()
+    if k >= 32:
+        qb, rb = orc.round_bf16(q), orc.round_bf16(r)
+        wb = orc.v0_search(qb, rb, threads=8)[0]
+        ixb = pkg.Index(torch.from_numpy(np.ascontiguousarray(rb.T)).cuda().to(torch.bfloat16), soa=True)
+        got = ixb.search(torch.from_numpy(qb).cuda().to(torch.bfloat16))
+        assert np.array_equal(got.cpu().numpy(), wb)
+        ixb.close()
