@@ -145,13 +145,13 @@ constexpr int F_LDS_BYTES = F_D * F_SLOT_BYTES;
 #define NNS_F_NW_BF16 8
 #endif
 
-template <int SPB>
+template <int SPB, int QB_>
 struct OpF32T {  // fp32 operands: float4 #b = operands of MFMA k-steps 4b .. 4b+3 (8 dims per fragment)
     static constexpr int kSPB = SPB;          // fragment steps per 32-point image block: KT = 8 * SPB
     static constexpr bool kTile16 = false;    // 32x32 MFMA tiles: a lane owns one query per query block
     static constexpr bool kLag = true;        // SIMD partners half a block out of phase (+1.3 % on C3)
     using Acc = AccSet;
-    static constexpr int kQB = NNS_F_QB_F32;
+    static constexpr int kQB = QB_;           // 4 * SPB resident operand registers per query block
     static constexpr int kNW = NNS_F_NW_F32;
 #ifndef NNS_F_PF
 #define NNS_F_PF 2
@@ -166,8 +166,11 @@ struct OpF32T {  // fp32 operands: float4 #b = operands of MFMA k-steps 4b .. 4b
         return acc;
     }
 };
-using OpF32 = OpF32T<16>;      // KT = 128
-using OpF32K32 = OpF32T<4>;    // KT = 32: the mid-range dimensionalities (k = 8 .. 32)
+using OpF32 = OpF32T<16, NNS_F_QB_F32>;      // KT = 128
+using OpF32K32 = OpF32T<4, NNS_F_QB_F32>;    // KT = 32: the mid-range dimensionalities (k = 8 .. 32)
+// KT = 256 (128 < k <= 256): the resident operands of ONE query block already take 128 registers,
+// a ring slot holds one 32-ref block (32 KiB), and the ring turns twice as often per MFMA
+using OpF32K256 = OpF32T<32, 1>;
 
 // bf16, KT = 256, 16 fragment steps per 32-ref block either way; two MFMA shapes:
 //
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     constexpr int SLOT_REFS = 32 * BPS;
     constexpr int F_PPW = F_SLOT_COORD / 1024 / F_NW;   // 1 KiB DMA pieces per wave per slot
     static_assert(32 % SPB == 0 && SPB >= 4, "a slot is 32 fragment steps");
-    static_assert(SLOT_REFS == 64 || SLOT_REFS == 256, "norm piece: one dword or one dwordx4 per lane");
+    static_assert(SLOT_REFS == 32 || SLOT_REFS == 64 || SLOT_REFS == 256, "norm piece: one dword or one dwordx4 per lane");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -374,10 +377,10 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         if (p < F_PPW) {
             const int piece = wave * F_PPW + p;
             dma16(a.rimg + gslot * F_SLOT_COORD + piece * 1024 + lane * 16, dst + piece * 1024);
-        } else if constexpr (SLOT_REFS == 64) {
+        } else if constexpr (SLOT_REFS <= 64) {
             // the slot's norms: every wave copies the same bytes to the same words (keeps each
-            // wave's DMA count per slot identical)
-            dma4(a.rnorm + gslot * 64 + lane, dst + F_SLOT_COORD);
+            // wave's DMA count per slot identical; a 32-ref slot also copies the next slot's 32)
+            dma4(a.rnorm + gslot * SLOT_REFS + lane, dst + F_SLOT_COORD);
         } else {
             dma16(a.rnorm + gslot * 256 + lane * 4, dst + F_SLOT_COORD);
         }
@@ -844,17 +847,21 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g)
     } else {
         if (k <= 32) kt = 32;          // OpF32K32: 4 fragment steps per block, 8 blocks per slot
         else if (k <= 128) kt = 128;
+        else if (k <= 256) kt = 256;   // OpF32K256: 32 fragment steps per block, 1 block per slot
     }
     if (!kt) {
-        set_error("MFMA filter: k = %d exceeds the %s tile depth", k, bf16 ? "bf16 (256)" : "fp32 (128)");
+        set_error("MFMA filter: k = %d exceeds the tile depth (256)", k);
         return NNS_ERR_UNSUPPORTED;
     }
     g->bf16 = bf16 ? 1 : 0;
     g->kt = kt;
     g->lpq = (bf16 && OpBF16Active::kTile16) ? 4 : 2;
-    const int qw = 32 * (bf16 ? OpBF16Active::kQB * OpBF16Active::kNW : OpF32::kQB * OpF32::kNW);   // queries per workgroup
+    // queries per workgroup
+    const int qw = 32 * (bf16 ? OpBF16Active::kQB * OpBF16Active::kNW
+                              : (kt == 256 ? OpF32K256::kQB * OpF32K256::kNW : OpF32::kQB * OpF32::kNW));
     g->m_pad = divup(m, qw) * qw;
-    const int slot_pts = (kt == 32) ? 256 : 64;   // refs per ring slot (32 fragment steps)
+    // refs per ring slot (32 fragment steps of 8 fp32 / 16 bf16 dims)
+    const int slot_pts = bf16 ? 64 : 32 * (32 / (kt / 8));
     g->n_pad = divup(n, slot_pts) * slot_pts;
     g->total_slots = g->n_pad / slot_pts;
     g->qgroups = g->m_pad / qw;
@@ -928,7 +935,9 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
     const size_t nwg = (size_t)g.qgroups * g.splits;
     if (clk && atoi(clk)) NNS_HIP(hipMalloc(&a.stamps, nwg * 4 * sizeof(unsigned long long)));
     const int rc = g.bf16 ? launch_filter_t<OpBF16Active>(g, a, st)
-                          : (g.kt == 32 ? launch_filter_t<OpF32K32>(g, a, st) : launch_filter_t<OpF32>(g, a, st));
+                          : (g.kt == 32    ? launch_filter_t<OpF32K32>(g, a, st)
+                             : g.kt == 256 ? launch_filter_t<OpF32K256>(g, a, st)
+                                           : launch_filter_t<OpF32>(g, a, st));
     if (a.stamps) {   // diagnostic: synchronous read-out, median clock over workgroups
         std::vector<unsigned long long> h(nwg * 4);
         NNS_HIP(hipStreamSynchronize(st));

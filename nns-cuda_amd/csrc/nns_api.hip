@@ -28,8 +28,9 @@ void set_error(const char *fmt, ...)
 
 using namespace nns;
 
-// one point of either tile image is 512 bytes: 128 fp32 dims or 256 bf16 dims
-static const size_t F_IMG_ROW_BYTES = 512;
+// one point of a tile image: 512 bytes (128 fp32 dims or 256 bf16 dims; the 32-deep fp32 tile is
+// allocated at the same size), 1 KiB for the 256-deep fp32 tile
+static size_t img_row_bytes(const FilterGeom &g) { return (!g.bf16 && g.kt > 128) ? (size_t)g.kt * 4 : 512; }
 // below this many queries the AUTO path skips the MFMA filter (and, in the whole-call
 // entry points, its ref pre-pass too)
 static const int kTinyM = 64;
@@ -210,7 +211,7 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
     }
     ix->profile = (flags & NNS_PROFILE) != 0;
 
-    const int kmax = bf16 ? 256 : 128;   // tile depth of the MFMA filter
+    const int kmax = 256;   // deepest tile of the MFMA filter (fp32 and bf16)
     int path = flags & NNS_PATH_MASK;
     // crossover: from k = 8 the MFMA filter (KT = 32 tile) beats 3k VALU ops per pair; bf16 tiles
     // are 256 deep, so they only pay from k = 32
@@ -242,7 +243,7 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
             size_t ws = 0;
             prep_workspace_bytes(g.kt, &ws);
             // + 512 rows: the filter's ring DMA runs two slots (64 or 256 refs each) past the last one
-            if (pool_alloc(&ix->rimg, (size_t)(g.n_pad + 512) * (F_IMG_ROW_BYTES)) != hipSuccess ||
+            if (pool_alloc(&ix->rimg, (size_t)(g.n_pad + 512) * img_row_bytes(g)) != hipSuccess ||
                 pool_alloc(&ix->rnorm, (size_t)(g.n_pad + 512) * sizeof(float)) != hipSuccess ||
                 pool_alloc(&ix->mean, (size_t)g.kt * sizeof(float)) != hipSuccess ||
                 pool_alloc(&ix->mean_ws, ws) != hipSuccess ||
@@ -321,7 +322,7 @@ static int ensure_query_ws(nns_index *ix, int m)
         ix->qnorm = nullptr;
         ix->amb_list = nullptr;
         ix->m_cap = 0;
-        if (pool_alloc(&ix->qimg, (size_t)gq.m_pad * (F_IMG_ROW_BYTES)) != hipSuccess ||
+        if (pool_alloc(&ix->qimg, (size_t)gq.m_pad * img_row_bytes(gq)) != hipSuccess ||
             pool_alloc(&ix->qnorm, (size_t)gq.m_pad * sizeof(float)) != hipSuccess ||
             pool_alloc(&ix->amb_list, (size_t)gq.m_pad * sizeof(int)) != hipSuccess) {
             set_error("query workspace allocation failed (m_pad=%d)", gq.m_pad);

@@ -266,6 +266,10 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, c
         hipLaunchKernelGGL(image_kernel<128>, dim3(blocks), dim3(256), 0, st, k, npts, pts, mean,
                            scale, pad_norm, img, norms, max_norm_bits, maxabs_bits);
         break;
+    case 256:
+        hipLaunchKernelGGL(image_kernel<256>, dim3(blocks), dim3(256), 0, st, k, npts, pts, mean,
+                           scale, pad_norm, img, norms, max_norm_bits, maxabs_bits);
+        break;
     default:
         set_error("prep: unsupported tile K %d", kt);
         return NNS_ERR_UNSUPPORTED;

@@ -22,7 +22,7 @@ def _check(pkg, orc, q, r, paths=("auto",), shards=(1,), want=None):
     if want is not None:
         assert np.array_equal(want_idx, want), "oracle disagrees with the golden vector"
     for path in paths:
-        if path == "mfma" and q.shape[1] > 128:
+        if path == "mfma" and q.shape[1] > 256:
             continue
         for s in shards:
             idx, dist = pkg.search(q, r, return_distances=True, shards=s, path=path)
@@ -241,9 +241,9 @@ def test_determinism_bitwise_repeatable(pkg):
 
 
 def test_errors_are_status_codes(pkg):
-    q = np.zeros((4, 200), np.float32)
+    q = np.zeros((4, 300), np.float32)
     with pytest.raises(pkg.NNSError) as e:
-        pkg.search(q, q, path="mfma")          # k > 128 not tiled on the MFMA path
+        pkg.search(q, q, path="mfma")          # k > 256 not tiled on the MFMA path
     assert e.value.status == 5
 
 
@@ -624,3 +624,23 @@ def test_dimension_major_refs(pkg, orc, shape):
         got = ixb.search(torch.from_numpy(qb).cuda().to(torch.bfloat16))
         assert np.array_equal(got.cpu().numpy(), wb)
         ixb.close()
+
+
+@pytest.mark.parametrize("shape", [(300, 5000, 256), (700, 20001, 200), (33, 4097, 129), (1100, 33000, 192)])
+def test_filter_k256_tile_shapes(pkg, orc, shape):
+    """128 < k <= 256 (fp32) runs the 256-deep MFMA tile: one query block per wave, one 32-ref
+    block per ring slot.  Ragged m / n / k vs the oracle, forced and under AUTO, whole and sharded;
+    near-duplicates force the exact re-rank of the candidate lists."""
+    m, n, k = shape
+    rng = np.random.default_rng(700 + k)
+    q = rng.random((m, k), dtype=np.float32)
+    r = rng.random((n, k), dtype=np.float32)
+    r[n // 2:n // 2 + 50] = r[:50]                       # exact duplicates: lowest index must win
+    q[:20] = r[:20] + rng.normal(0, 1e-4, (20, k)).astype(np.float32)
+    _check(pkg, orc, q, r, paths=("mfma", "auto"), shards=(1, 3))
+    ix = pkg.Index(torch.from_numpy(r).cuda())
+    ix.search(torch.from_numpy(q).cuda())
+    st = ix.stats()
+    if m >= 64:      # (a handful of queries stays on the exact lane-per-ref kernel under AUTO)
+        assert st["path"] == 2 and st["k_tile"] == 256, st
+    ix.close()
