@@ -200,6 +200,12 @@ int nns_device_count(void);
 const char *nns_strerror(int status);
 const char *nns_last_error(void); /* thread-local detail of the last failure */
 int nns_version(void);            /* major * 1000 + minor */
+/* Explicit replacement for the reference's hidden WarmUP static (ten V9 calls before main(),
+ * core.cu:1900-1933): runs one tiny search through every kernel family (exact lane-per-query and
+ * lane-per-ref, the 32 / 128 / 256-deep fp32 MFMA filters, the bf16 filter) on `device`, so that
+ * code-object loading, the filter's LDS opt-in and the first pool allocations are paid here and
+ * not inside a timed call.  Optional: every entry point works without it. */
+int nns_warmup(int device);
 /* The library parks freed device workspaces (queries/refs staging, tile images, candidate
  * lists) in a per-device pool instead of returning them to the runtime on every call — the
  * reference allocates and frees on every cudaCall (core.cu:793-802).  nns_trim() gives all

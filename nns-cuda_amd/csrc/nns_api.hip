@@ -671,6 +671,58 @@ int nns_search_bf16_ex(int k, int m, int n, const uint16_t *s_points, const uint
     return search_host_impl(k, m, n, s_points, r_points, 1, idx_out, dist_out, num_shards, flags, device);
 }
 
+int nns_warmup(int device)
+{
+    NNS_TRY(ensure_device_ok(device));
+    // (k, m, n, bf16): K1a, K1b, the three fp32 tile depths, the bf16 filter
+    static const int shapes[][4] = {{3, 64, 512, 0},  {16, 1, 512, 0},   {16, 64, 512, 0},
+                                    {64, 64, 512, 0}, {200, 64, 512, 0}, {64, 64, 512, 1}};
+    const int kmax = 200, mmax = 64, nmax = 512;
+    float *q = (float *)malloc(sizeof(float) * kmax * mmax), *r = (float *)malloc(sizeof(float) * kmax * nmax);
+    int *idx = (int *)malloc(sizeof(int) * mmax);
+    if (!q || !r || !idx) {
+        free(q);
+        free(r);
+        free(idx);
+        return NNS_ERR_NOMEM;
+    }
+    unsigned x = 12345u;   // any finite values do
+    for (int i = 0; i < kmax * mmax; ++i) q[i] = (float)((x = x * 1664525u + 1013904223u) >> 8) * (1.0f / 16777216.0f);
+    for (int i = 0; i < kmax * nmax; ++i) r[i] = (float)((x = x * 1664525u + 1013904223u) >> 8) * (1.0f / 16777216.0f);
+    int rc = NNS_OK;
+    for (const auto &sh : shapes) {
+        if (sh[3]) {
+            // the same numbers as bf16 bit patterns (truncated: this is a warm-up, not a result)
+            uint16_t *qb = (uint16_t *)malloc(sizeof(uint16_t) * sh[0] * sh[1]);
+            uint16_t *rb = (uint16_t *)malloc(sizeof(uint16_t) * sh[0] * sh[2]);
+            if (qb && rb) {
+                for (int i = 0; i < sh[0] * sh[1]; ++i) {
+                    unsigned u;
+                    memcpy(&u, &q[i], 4);
+                    qb[i] = (uint16_t)(u >> 16);
+                }
+                for (int i = 0; i < sh[0] * sh[2]; ++i) {
+                    unsigned u;
+                    memcpy(&u, &r[i], 4);
+                    rb[i] = (uint16_t)(u >> 16);
+                }
+                rc = search_host_impl(sh[0], sh[1], sh[2], qb, rb, 1, idx, nullptr, 1, NNS_PATH_AUTO, device);
+            } else {
+                rc = NNS_ERR_NOMEM;
+            }
+            free(qb);
+            free(rb);
+        } else {
+            rc = search_host_impl(sh[0], sh[1], sh[2], q, r, 0, idx, nullptr, 1, NNS_PATH_AUTO, device);
+        }
+        if (rc != NNS_OK) break;
+    }
+    free(q);
+    free(r);
+    free(idx);
+    return rc;
+}
+
 int nns_search_f32(int k, int m, int n, const float *s_points, const float *r_points, int **results)
 {
     if (!results) {

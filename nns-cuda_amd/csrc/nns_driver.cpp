@@ -7,7 +7,7 @@
 // float(rand() / double(RAND_MAX)): main.cu:10-13, 27-34, 54, 64), wall-clock timing of the
 // WHOLE call including device malloc + H2D + D2H (main.cu:73-75, utils.h:9-13) and the
 // output line "CudaCall v, k, m, n, ms" (main.cu:76).  The reference's static WarmUP object
-// (core.cu:1900-1933: ten hidden V9 calls before main) becomes one explicit warm-up call.
+// (core.cu:1900-1933: ten hidden V9 calls before main) becomes one explicit nns_warmup() call.
 //
 // It adds an FNV-1a digest of the result indices per sample so a run can be compared with
 // the oracle's digests (tests/test_driver.py) — the driver itself contains no CPU search.
@@ -96,10 +96,11 @@ int main(int argc, char **argv)
         all_gpus ? &mi355x::cudaCallAllGpus : &mi355x::cudaCall;
 
     if (warmup) {   // explicit stand-in for the reference's WarmUP static (core.cu:1900-1933)
-        float q[1] = {0.5f}, r[4] = {0.1f, 0.2f, 0.6f, 0.9f};
-        int *res = nullptr;
-        (*func)(1, 1, 4, q, r, &res);
-        free(res);
+        const int rc = nns_warmup(0);
+        if (rc != NNS_OK) {
+            printf("Error: %s:%d, code:%d, reason: %s (%s) \n", __FILE__, __LINE__, rc, nns_strerror(rc), nns_last_error());
+            return 1;
+        }
     }
 
     const int v = 100;   // version tag printed where the reference prints v = 0..13

@@ -38,7 +38,7 @@ ABI_SYMBOLS = (
     "nns_keys_unpack", "nns_fill_uniform", "nns_device_count", "nns_strerror",
     "nns_last_error", "nns_version", "nns_selftest_mfma",
     "nns_index_create_bf16", "nns_index_search_bf16", "nns_search_bf16_ex", "nns_search_f32_multi",
-    "nns_trim",
+    "nns_trim", "nns_warmup",
 )
 
 
@@ -102,6 +102,7 @@ def _load() -> ctypes.CDLL:
     for name in ABI_SYMBOLS:
         if name not in ("nns_strerror", "nns_last_error", "nns_trim"):
             getattr(lib, name).restype = c_int
+    lib.nns_warmup.argtypes = [c_int]
     lib.nns_trim.argtypes = []
     lib.nns_trim.restype = ctypes.c_size_t
     return lib
@@ -303,6 +304,11 @@ class Index:
             self.close()
         except Exception:
             pass
+
+
+def warmup(device: int = 0) -> None:
+    """nns_warmup: touch every kernel family once (code load, LDS opt-in, pool)."""
+    _check(lib.nns_warmup(device), "nns_warmup")
 
 
 def trim() -> int:
