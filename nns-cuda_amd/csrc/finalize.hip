@@ -72,6 +72,10 @@ __device__ __forceinline__ float v0_distance(const T *qi, const T *rj, int k, bo
     return sum;
 }
 
+// One wave per list UNIT (the 64 lane-lists the filter's wave wrote for 32 queries x 2 lanes or 16
+// queries x 4 lanes): lane L walks list lane L, so every load of the [entry][lane] layout is a
+// fully coalesced 512-B row, the lpq lists of a query are walked in parallel, and the per-query
+// minimum / best key is a 1- or 2-step xor shuffle across the lanes L ^ 32 (^ 16).
 template <typename T>
 __global__ __launch_bounds__(256) void finalize_kernel(
     int kt, int bf16, int lpq, int m_pad, int splits, int k, int m, int n, const T *__restrict__ q,
@@ -79,57 +83,69 @@ __global__ __launch_bounds__(256) void finalize_kernel(
     const float *__restrict__ qnorm, DevScalars *__restrict__ scal, int64_t index_base,
     nns_key *__restrict__ keys, int *__restrict__ amb_list)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
     const int ush = lpq == 4 ? 4 : 5, qmask = (1 << ush) - 1;   // queries per list unit: 16 or 32
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);       // wave-uniform
+    const int units = m_pad >> ush;
+    if (unit >= units) return;
+    const int i = (unit << ush) + (lane & qmask);               // this lane's query
+    const bool live = i < m;
 
     bool fallback = scal->q_maxabs_bits >= kHugeBits || scal->r_maxabs_bits >= kHugeBits;
     float a = __builtin_inff();
-    if (!fallback) {
-        for (int s = 0; s < splits; ++s)
-            for (int h = 0; h < lpq; ++h) {
-                // [split][unit][entry][lane]: unit = 64 / lpq queries, lane = qpu * h + (i % qpu)
-                const size_t lblk = (size_t)s * (m_pad >> ush) + (i >> ush);
-                const int ln = (h << ush) + (i & qmask);
-                const int cw = counts[lblk * 64 + ln];
-                if (cw & kCandOverflow) fallback = true;
-                const int c = (cw & kCandCountMask) < kCandCap ? (cw & kCandCountMask) : kCandCap;
-                const CandEntry *l = lists + lblk * (kCandCap * 64) + ln;
-                for (int e = 0; e < c; ++e) a = fminf(a, l[e * 64].s);
-            }
+    int over = 0;
+    if (!fallback && live) {
+        for (int s = 0; s < splits; ++s) {
+            const size_t lblk = (size_t)s * units + unit;
+            const int cw = counts[lblk * 64 + lane];
+            if (cw & kCandOverflow) over = 1;
+            const int c = (cw & kCandCountMask) < kCandCap ? (cw & kCandCountMask) : kCandCap;
+            const CandEntry *l = lists + lblk * (kCandCap * 64) + lane;
+            for (int e = 0; e < c; ++e) a = fminf(a, l[e * 64].s);
+        }
     }
-    if (!(a < __builtin_inff())) fallback = true;
+    // combine the query's lpq lists: lanes that differ in the bits above the query index
+    for (int off = 32; off >= (1 << ush); off >>= 1) {
+        a = fminf(a, __shfl_xor(a, off, 64));
+        over |= __shfl_xor(over, off, 64);
+    }
+    if (over || !(a < __builtin_inff())) fallback = true;
 
     nns_key best = NNS_KEY_NONE;
-    if (!fallback) {
+    if (!fallback && live) {
         const TauConsts tc = tau_consts(kt, qnorm[i], __uint_as_float(scal->ymax2_bits), bf16 != 0);
         const float thr = a + tau_of(tc, a);
         const T *qi = q + (size_t)i * k;
         const bool vec = (k & 3) == 0 && (((uintptr_t)q | (uintptr_t)r) & (4 * sizeof(T) - 1)) == 0;
-        for (int s = 0; s < splits; ++s)
-            for (int h = 0; h < lpq; ++h) {
-                const size_t lblk = (size_t)s * (m_pad >> ush) + (i >> ush);
-                const int ln = (h << ush) + (i & qmask);
-                const int cw = counts[lblk * 64 + ln] & kCandCountMask;
-                const int c = cw < kCandCap ? cw : kCandCap;
-                const CandEntry *l = lists + lblk * (kCandCap * 64) + ln;
-                for (int e = 0; e < c; ++e) {
-                    const CandEntry ce = l[e * 64];
-                    if (ce.s <= thr && ce.j < n) {
-                        const float sum = v0_distance(qi, r + (size_t)ce.j * k, k, vec);
-                        const nns_key key = make_key(sum, index_base + ce.j);
-                        best = key < best ? key : best;
-                    }
+        for (int s = 0; s < splits; ++s) {
+            const size_t lblk = (size_t)s * units + unit;
+            const int cw = counts[lblk * 64 + lane] & kCandCountMask;
+            const int c = cw < kCandCap ? cw : kCandCap;
+            const CandEntry *l = lists + lblk * (kCandCap * 64) + lane;
+            for (int e = 0; e < c; ++e) {
+                const CandEntry ce = l[e * 64];
+                if (ce.s <= thr && ce.j < n) {
+                    const float sum = v0_distance(qi, r + (size_t)ce.j * k, k, vec);
+                    const nns_key key = make_key(sum, index_base + ce.j);
+                    best = key < best ? key : best;
                 }
             }
-        // every candidate NaN/INF cannot happen with bounded inputs; be safe anyway
-        if (best == NNS_KEY_NONE) fallback = true;
+        }
     }
-    keys[i] = best;
-    if (fallback) {
-        keys[i] = NNS_KEY_NONE;
-        const int pos = atomicAdd(&scal->amb_count, 1);
-        amb_list[pos] = i;
+    for (int off = 32; off >= (1 << ush); off >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)best, off, 64);
+        const unsigned hi = __shfl_xor((unsigned)(best >> 32), off, 64);
+        const nns_key o = ((nns_key)hi << 32) | lo;
+        best = o < best ? o : best;
+    }
+    // every candidate NaN/INF cannot happen with bounded inputs; be safe anyway
+    if (best == NNS_KEY_NONE) fallback = true;
+    if (live && lane <= qmask) {   // one lane per query writes
+        keys[i] = fallback ? (nns_key)NNS_KEY_NONE : best;
+        if (fallback) {
+            const int pos = atomicAdd(&scal->amb_count, 1);
+            amb_list[pos] = i;
+        }
     }
 }
 
@@ -226,11 +242,11 @@ int launch_finalize(const FilterGeom &g, int k, int m, int n, const void *q, con
         return NNS_OK;
     }
     if (g.bf16)
-        hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(divup(m, 256)), dim3(256), 0, st, g.kt, 1, g.lpq, g.m_pad,
+        hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(divup(g.m_pad / (64 / g.lpq), 4)), dim3(256), 0, st, g.kt, 1, g.lpq, g.m_pad,
                            g.splits, k, m, n, (const uint16_t *)q, (const uint16_t *)r, lists, counts, qnorm,
                            scal, index_base, keys, amb_list);
     else
-        hipLaunchKernelGGL(finalize_kernel<float>, dim3(divup(m, 256)), dim3(256), 0, st, g.kt, 0, g.lpq, g.m_pad,
+        hipLaunchKernelGGL(finalize_kernel<float>, dim3(divup(g.m_pad / (64 / g.lpq), 4)), dim3(256), 0, st, g.kt, 0, g.lpq, g.m_pad,
                            g.splits, k, m, n, (const float *)q, (const float *)r, lists, counts, qnorm, scal,
                            index_base, keys, amb_list);
     NNS_HIP(hipGetLastError());
