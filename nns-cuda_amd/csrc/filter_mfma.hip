@@ -51,6 +51,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
 #include <vector>
 #include "nns_internal.h"
 
@@ -901,12 +902,12 @@ static int launch_filter_t(const FilterGeom &g, const FilterArgs &args, hipStrea
     // 16x16 tiles: + 2 KiB per wave for the lanes' tau constants
     constexpr int lds_bytes = F_LDS_BYTES + (OP::kTile16 ? OP::kNW * 2048 : 0);
     // > 64 KiB of dynamic LDS needs the opt-in, once per device
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];   // (two threads racing here both set it: harmless)
     int dev = 0;
     NNS_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
         NNS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3(g.qgroups, g.splits), dim3(OP::kNW * 64), lds_bytes, st, args);
     NNS_HIP(hipGetLastError());

@@ -211,6 +211,7 @@ extern "C" int nns_search_f32_multi(int k, int m, int n, const float *s_points, 
     }
     for (int g = 0; g < G; ++g) {
         (void)hipSetDevice(jobs[g].device);
+        (void)hipDeviceSynchronize();   // the blocks go back to the pool: nothing may still use them
         pool_free(jobs[g].q_d);
         pool_free(jobs[g].r_d);
         pool_free(jobs[g].keys);
