@@ -115,6 +115,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (NOT a measurement):
+    # every rank on cuda:0, keys exchanged through gloo on the host instead of RCCL
+    ap.add_argument("--rehearse-one-gpu", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="rank 0 checks the merged indices against the unsharded search")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,6 +130,8 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -133,7 +139,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = graft.load_package()
     m, n_local, k, dtype = WORKLOADS[args.workload]
@@ -191,7 +200,7 @@ def main():
         stage[f] += st[f] * (args.steps - done)
     amb = st["ambiguous"]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     for f in stage:
@@ -232,6 +241,20 @@ def main():
                        "ambiguous_queries": amb, "stage_ms": {f: round(v, 4) for f, v in stage.items()}},
             "roofline": roof,
         }
+        if args.rehearse_one_gpu:
+            out["rehearsal"] = "all ranks on one GPU, gloo exchange: NOT a measurement"
+        if args.verify:
+            # the merged answer must equal one unsharded search over all n_total refs
+            r_all = torch.empty((n_total, k), dtype=torch.float32, device=dev)
+            pkg.fill_uniform(r_all, seed, m * k)
+            if dtype == "bf16":
+                r_all = r_all.to(torch.bfloat16)
+            ix_all = pkg.Index(r_all)
+            want = ix_all.search(q)
+            torch.cuda.synchronize()
+            out["verified_vs_unsharded"] = bool(torch.equal(want, idx))
+            ix_all.close()
+            del r_all
         if world == 1 and not args.no_cpu_baseline:
             orc = graft.load_oracle()          # cpu_baseline leg only
             out["cpu_baseline"] = cpu_baseline(orc, q[:4096].float().cpu().numpy(), r.float(), idx.cpu().numpy())

@@ -644,3 +644,25 @@ def test_filter_k256_tile_shapes(pkg, orc, shape):
     if m >= 64:      # (a handful of queries stays on the exact lane-per-ref kernel under AUTO)
         assert st["path"] == 2 and st["k_tile"] == 256, st
     ix.close()
+
+
+@pytest.mark.timeout(600)
+def test_bench_multirank_rehearsal():
+    """bench.py's N > 1 code path (rank -> ref shard, index_base, min all-reduce of the keys,
+    rank-0 report) with two ranks on this box's one GPU and the exchange through gloo: the merged
+    indices must equal one unsharded search over all refs.  (The RCCL run itself needs one GPU per
+    rank: the driver's 8-GPU bench.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "c3s", "--rehearse-one-gpu", "--verify"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["n"] == 2 * d["config"]["refs_per_gpu"]
+    assert d["verified_vs_unsharded"] is True
+    assert d["scaling"] == "weak" and "cpu_baseline" not in d
