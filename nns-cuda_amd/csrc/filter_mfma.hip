@@ -10,7 +10,7 @@
 // (centred by K2; c = 0 on the bf16 path),
 //     s(i, j) = |y'_j|^2 - 2 x'_i . y'_j            ( = ||q_i - r_j||^2 - |x'_i|^2 )
 // has the same argmin over j.  -2 * Y' * X'^T is a dense GEMM on the matrix cores
-// (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain; v_mfma_f32_32x32x16_bf16: bf16 inputs,
+// (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain; v_mfma_f32_16x16x32_bf16: bf16 inputs,
 // fp32 accumulate) with |y'_j|^2 preloaded as the accumulator's initial value, so the
 // finished accumulator IS s(i, j) and the matrix never leaves the registers.
 //
@@ -25,14 +25,14 @@
 // those few candidates with V0's own arithmetic: indices come out bit-identical to V0
 // although the filter itself is approximate.
 //
-// Geometry:
+// Geometry (fp32; what the bf16 instantiation does differently is described at OpBF16):
 //   * MFMA A = refs (rows of the 32x32 tile), B = queries (columns): the C layout puts
 //     a query on a lane (col = lane & 31) and 16 refs in the lane's 16 accumulator
 //     registers, so the running state is per lane and needs no cross-lane traffic.
-//   * a wave owns 32 queries; their B operands for all of K (64 VGPRs) are loaded once
-//     and stay resident.  A workgroup is 8 waves = 256 queries; all 8 waves consume the
-//     same stream of ref blocks from LDS (a block fetched once feeds 256 queries; the
-//     reference's V7 re-reads it per query).
+//   * a wave owns 64 queries (two blocks of 32; one block at the 256-deep tile); their B
+//     operands for all of K (128 VGPRs) are loaded once and stay resident.  A workgroup is
+//     8 waves = 512 queries; all 8 waves consume the same stream of ref blocks from LDS (a
+//     block fetched once feeds 512 queries; the reference's V7 re-reads it per query).
 //   * refs stream through a 4-slot LDS ring (slot = 64 refs = 32 KiB of K2's tile image
 //     + 256 B of norms) filled by LDS-DMA (global_load_lds_dwordx4: the image is stored in
 //     LDS order, so the copy is linear, 1 KiB per wave-instruction), waited for with
@@ -43,11 +43,12 @@
 //     after the barrier), so one partner's epilogue / accumulator re-seed / LDS latency
 //     falls in the middle of the other's MFMA chain instead of both stalling together
 //     at every block boundary (MI355X guide, "Two waves per SIMD", item 9).
-//   * grid = (m_pad / 256) x splits; splits > 1 only when there are fewer than 256
-//     query groups (one resident workgroup per CU).
+//   * grid = (m_pad / 512) x splits; the split count minimises rounds x work per
+//     workgroup (one resident workgroup per CU), see filter_plan.
 //
 // Roofline: MFMA-bound.  fp32: 64 MFMAs x 64 cycles per 32x32x128 tile per SIMD; bf16:
-// 16 MFMAs x 32 cycles per 32x32x256 tile.  Algorithmic HBM traffic = the images once.
+// 32 MFMAs x 16 cycles per 32x32x256 tile (four 16x16 tiles x 8 k-steps).  Algorithmic HBM
+// traffic = the images once.
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
