@@ -743,7 +743,9 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             // interval: hipcc is free to split / copy those accumulators at the loop back-edge
             // (it did: v_mov of single elements right behind the MFMAs = stale reads).  Whatever it
             // does with them now happens behind the 8 wait states their readers need.
+#ifndef NNS_F_NOLATCHFENCE   // (timing experiments only: without it the results are wrong)
             if constexpr (T16) OP::mma16_tail_fence(acc);
+#endif
         }
     }
     if constexpr (T16) {   // ref tile 1 of the last block is still to be retired

@@ -5,6 +5,7 @@
 // 761-853 for V8), split so that the device-resident part (index create +
 // search on the caller's stream) can be timed and sharded on its own.
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -406,8 +407,9 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
     const FilterGeom &g = ix->geom;
     if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_BEGIN], st);
     // reset the per-search scalars (q max-abs, ambiguous count); keep the ref-side ones
-    NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned), st));
-    NNS_HIP(hipMemsetAsync(&ix->scal->amb_count, 0, sizeof(int), st));
+    static_assert(offsetof(DevScalars, amb_count) == offsetof(DevScalars, q_maxabs_bits) + sizeof(unsigned),
+                  "per-search scalars must be adjacent");
+    NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned) + sizeof(int), st));
     if (bf16)
         NNS_TRY(launch_prep_image_bf16(NNS_BF16_TILE16 ? 1 : 0, ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
                                        nullptr, &ix->scal->q_maxabs_bits, st));

@@ -147,8 +147,9 @@ __host__ __device__ inline float tau_of(const TauConsts &t, float a)
 // device-side scalars shared between kernels of one index
 struct DevScalars {
     unsigned r_maxabs_bits;  // max |r| bits (NaN/INF/huge detection)
-    unsigned q_maxabs_bits;  // max |q| bits
     unsigned ymax2_bits;     // max centred squared norm over refs
+    // the two per-search words are adjacent: one 8-byte memset resets them
+    unsigned q_maxabs_bits;  // max |q| bits
     int amb_count;           // number of ambiguous queries
     unsigned pad[4];
 };
