@@ -70,6 +70,13 @@ enum {
     NNS_PATH_MASK = 3,
     NNS_PROFILE = 16,    /* record HIP-event timings per stage (adds syncs at read-out) */
     NNS_MULTI_VIRTUAL = 32, /* nns_search_f32_multi: allow more shards than GPUs (rehearsal) */
+    NNS_FILTER_BF16 = 128, /* OPT-IN, fp32 points only, 32 <= k <= 256: run the MFMA filter on the centred points
+                          * rounded to bf16 (v_mfma_f32_16x16x32_bf16: 16x the fp32 MFMA rate) with a margin tau
+                          * widened by the rounding bound 2^-6 |x'||y'|, then re-rank the candidates with V0's fp32
+                          * arithmetic on the ORIGINAL fp32 points as usual.  Indices and distances are the same
+                          * bits as without the flag (the filter only decides which refs are re-ranked); queries
+                          * whose candidate lists overflow fall back to the exact scan.  Never chosen by
+                          * NNS_PATH_AUTO and not what bench.py measures for the fp32 configurations. */
     NNS_REFS_SOA = 64    /* the reference points are given dimension-major, r[t * n + j] (a dense [k][n]
                           * array: the layout v4::mat_inv_kernel produces, core.cu:293-306, :327) instead
                           * of r[j * k + t]; queries stay [m][k].  The library transposes once on the

@@ -191,8 +191,9 @@ using OpF32K256 = OpF32T<32, 1>;
 // not hide it, measured), which cost 7-9 % of this kernel.  Two v_min per MFMA gap fit the 8
 // issue cycles a 16x16x32 leaves free, so the reduction of tile rt's finished scores is spread
 // over k-step 1 of tile 1 - rt, and the threshold test + (rare) slow path follow at k-step 2.
-struct OpBF16 {
-    static constexpr int kSPB = 16;
+template <int SPB_>
+struct OpBF16T {
+    static constexpr int kSPB = SPB_;         // 16: KT = 256 (8 k-steps per 16-ref tile); 8: KT = 128 (4 k-steps)
     static constexpr bool kTile16 = true;
     static constexpr bool kLag = false;       // lock-step SIMD partners (lagging them: +1..4 % time on C5)
     using Acc = AccSet16;
@@ -236,6 +237,9 @@ struct OpBF16 {
         asm volatile("s_nop 7" : "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13));
     }
 };
+using OpBF16 = OpBF16T<16>;       // KT = 256
+using OpBF16K128 = OpBF16T<8>;    // KT = 128: k <= 128 without padding to 256 (half the MFMAs)
+
 
 // OpBF16T32: v_mfma_f32_32x32x16_bf16 (the first version; kept for A/B builds with
 // -DNNS_BF16_TILE32): 16 bytes = 8 bf16 = one operand, lane = query, 16 refs per lane.
@@ -295,7 +299,7 @@ struct FilterArgs {
     CandEntry *lists;       // [splits][m_pad/32][kCandCap][64 lanes]
     int *counts;            // [splits][m_pad/32][64 lanes]
     int total_slots, slots_per_split, m_pad, kt;
-    int bf16;
+    int bf16;               // tau mode: 0 fp32 operands, 1 bf16 points, 2 fp32 points rounded to bf16 operands
     unsigned long long *stamps;   // diagnostic (NNS_FILTER_CLOCK): per-workgroup s_memtime / s_memrealtime
 };
 
@@ -309,7 +313,8 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     constexpr int SLOT_REFS = 32 * BPS;
     constexpr int F_PPW = F_SLOT_COORD / 1024 / F_NW;   // 1 KiB DMA pieces per wave per slot
     static_assert(32 % SPB == 0 && SPB >= 4, "a slot is 32 fragment steps");
-    static_assert(SLOT_REFS == 32 || SLOT_REFS == 64 || SLOT_REFS == 256, "norm piece: one dword or one dwordx4 per lane");
+    static_assert(SLOT_REFS == 32 || SLOT_REFS == 64 || SLOT_REFS == 128 || SLOT_REFS == 256,
+                  "norm piece: one dword or one dwordx4 per lane");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
 #pragma unroll
             for (int b = 0; b < NBQ; ++b) bq[st][b] = src[(st * NBQ + b) * 64];
             tc[st] = tau_consts(a.kt, a.qnorm[qblk0 * 32 + st * QPS + (lane & (QPS - 1))],
-                                __uint_as_float(a.scal->ymax2_bits), a.bf16 != 0);
+                                __uint_as_float(a.scal->ymax2_bits), a.bf16);
         }
     }
     // Pin the loads here: hipcc must wait for them BEFORE the ring starts, not with a
@@ -379,12 +384,12 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         if (p < F_PPW) {
             const int piece = wave * F_PPW + p;
             dma16(a.rimg + gslot * F_SLOT_COORD + piece * 1024 + lane * 16, dst + piece * 1024);
-        } else if constexpr (SLOT_REFS <= 64) {
+        } else if constexpr (SLOT_REFS <= 64) {   // (128- and 256-ref slots: one dwordx4 piece of 256 norms)
             // the slot's norms: every wave copies the same bytes to the same words (keeps each
             // wave's DMA count per slot identical; a 32-ref slot also copies the next slot's 32)
             dma4(a.rnorm + gslot * SLOT_REFS + lane, dst + F_SLOT_COORD);
         } else {
-            dma16(a.rnorm + gslot * 256 + lane * 4, dst + F_SLOT_COORD);
+            dma16(a.rnorm + gslot * SLOT_REFS + lane * 4, dst + F_SLOT_COORD);
         }
     };
     auto issue = [&](int s) __attribute__((always_inline)) {
@@ -585,7 +590,9 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     auto t16_step = [&](typename OP::Acc &acc, const float4 &frag, int blk_global, auto b_c) __attribute__((always_inline)) {
         if constexpr (T16) {
             constexpr int b = decltype(b_c)::value;
-            constexpr int rt = b >> 3, ks = b & 7, ot = 1 - rt;
+            constexpr int NKS = SPB / 2;              // k-steps of 32 dims per 16-ref tile
+            static_assert(NKS >= 3, "the other tile is retired at k-steps 1 and 2");
+            constexpr int rt = b / NKS, ks = b % NKS, ot = 1 - rt;
             static_for<4>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int qt = decltype(qc)::value;
                 if constexpr (ks == 0) OP::mma16_seed(frag, bq[qt][0], acc.template at<rt, qt>(), rt == 0 ? nseed0 : nseed1);
@@ -678,8 +685,8 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             if constexpr (T16) {
                 // norms two steps ahead: tile 1 of this block; tile 0 of the next block (next ring
                 // slot after the slot's last block: confirmed by this interval's barrier)
-                if constexpr (b == 6) seed16(cur, blk, I1c{});
-                if constexpr (b == 14) seed16(blk + 1 < BPS ? cur : nxt, (blk + 1) % BPS, I0c{});
+                if constexpr (b == SPB / 2 - 2) seed16(cur, blk, I1c{});
+                if constexpr (b == SPB - 2) seed16(blk + 1 < BPS ? cur : nxt, (blk + 1) % BPS, I0c{});
             } else if constexpr (b == 0) seed(acc, cur, blk);   // a tile is seeded right where it starts
             // (LAG 1, very first interval: its first LAGOFF steps chew on a not-yet-written ring
             //  slot; that accumulator is discarded below and re-seeded at the next tile)
@@ -843,11 +850,13 @@ int launch_mfma_selftest(int kt, int bf16, const float *a, const float *b, const
 }
 
 // ---- planning + launch ---------------------------------------------------------------
-int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g)
+int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
 {
+    if (mixed) bf16 = true;   // fp32 points, bf16 operands: the bf16 filter's geometry
     int kt = 0;
     if (bf16) {
-        if (k <= 256) kt = 256;
+        if (k <= 128) kt = 128;        // OpBF16K128: 4 k-steps per 16-ref tile, 4 blocks per slot
+        else if (k <= 256) kt = 256;
     } else {
         if (k <= 32) kt = 32;          // OpF32K32: 4 fragment steps per block, 8 blocks per slot
         else if (k <= 128) kt = 128;
@@ -858,6 +867,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g)
         return NNS_ERR_UNSUPPORTED;
     }
     g->bf16 = bf16 ? 1 : 0;
+    g->mixed = mixed ? 1 : 0;
     g->kt = kt;
     g->lpq = (bf16 && OpBF16Active::kTile16) ? 4 : 2;
     // queries per workgroup
@@ -865,7 +875,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g)
                               : (kt == 256 ? OpF32K256::kQB * OpF32K256::kNW : OpF32::kQB * OpF32::kNW));
     g->m_pad = divup(m, qw) * qw;
     // refs per ring slot (32 fragment steps of 8 fp32 / 16 bf16 dims)
-    const int slot_pts = bf16 ? 64 : 32 * (32 / (kt / 8));
+    const int slot_pts = bf16 ? 32 * (32 / (kt / 16)) : 32 * (32 / (kt / 8));
     g->n_pad = divup(n, slot_pts) * slot_pts;
     g->total_slots = g->n_pad / slot_pts;
     g->qgroups = g->m_pad / qw;
@@ -933,12 +943,12 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
     a.slots_per_split = g.slots_per_split;
     a.m_pad = g.m_pad;
     a.kt = g.kt;
-    a.bf16 = g.bf16;
+    a.bf16 = g.mixed ? 2 : g.bf16;
     a.stamps = nullptr;
     const char *clk = getenv("NNS_FILTER_CLOCK");
     const size_t nwg = (size_t)g.qgroups * g.splits;
     if (clk && atoi(clk)) NNS_HIP(hipMalloc(&a.stamps, nwg * 4 * sizeof(unsigned long long)));
-    const int rc = g.bf16 ? launch_filter_t<OpBF16Active>(g, a, st)
+    const int rc = g.bf16 ? (g.kt == 128 ? launch_filter_t<OpBF16K128>(g, a, st) : launch_filter_t<OpBF16Active>(g, a, st))
                           : (g.kt == 32    ? launch_filter_t<OpF32K32>(g, a, st)
                              : g.kt == 256 ? launch_filter_t<OpF32K256>(g, a, st)
                                            : launch_filter_t<OpF32>(g, a, st));

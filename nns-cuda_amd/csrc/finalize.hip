@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(
 
     nns_key best = NNS_KEY_NONE;
     if (!fallback && live) {
-        const TauConsts tc = tau_consts(kt, qnorm[i], __uint_as_float(scal->ymax2_bits), bf16 != 0);
+        const TauConsts tc = tau_consts(kt, qnorm[i], __uint_as_float(scal->ymax2_bits), bf16);
         const float thr = a + tau_of(tc, a);
         const T *qi = q + (size_t)i * k;
         const bool vec = (k & 3) == 0 && (((uintptr_t)q | (uintptr_t)r) & (4 * sizeof(T) - 1)) == 0;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
 
     nns_key best = NNS_KEY_NONE;
     if (!fallback) {
-        const TauConsts tc = tau_consts(kt, qnorm[i], __uint_as_float(scal->ymax2_bits), bf16 != 0);
+        const TauConsts tc = tau_consts(kt, qnorm[i], __uint_as_float(scal->ymax2_bits), bf16);
         const float thr = a + tau_of(tc, a);
         const T *qi = q + (size_t)i * k;
         const bool vec = (k & 3) == 0 && (((uintptr_t)q | (uintptr_t)r) & (4 * sizeof(T) - 1)) == 0;
@@ -229,24 +229,26 @@ int launch_finalize(const FilterGeom &g, int k, int m, int n, const void *q, con
                     const CandEntry *lists, const int *counts, const float *qnorm, DevScalars *scal,
                     int64_t index_base, nns_key *keys, int *amb_list, hipStream_t st)
 {
+    const int mode = g.mixed ? 2 : g.bf16;        // tau mode (nns_internal.h)
+    const bool data_bf16 = g.bf16 && !g.mixed;    // element type of q / r
     if (g.splits >= 4) {   // few queries, many lists per query: one wave per query
-        if (g.bf16)
-            hipLaunchKernelGGL(finalize_wave_kernel<uint16_t>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, 1,
+        if (data_bf16)
+            hipLaunchKernelGGL(finalize_wave_kernel<uint16_t>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, mode,
                                g.lpq, g.m_pad, g.splits, k, m, n, (const uint16_t *)q, (const uint16_t *)r, lists,
                                counts, qnorm, scal, index_base, keys, amb_list);
         else
-            hipLaunchKernelGGL(finalize_wave_kernel<float>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, 0, g.lpq, g.m_pad,
+            hipLaunchKernelGGL(finalize_wave_kernel<float>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, mode, g.lpq, g.m_pad,
                                g.splits, k, m, n, (const float *)q, (const float *)r, lists, counts, qnorm, scal,
                                index_base, keys, amb_list);
         NNS_HIP(hipGetLastError());
         return NNS_OK;
     }
-    if (g.bf16)
-        hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(divup(g.m_pad / (64 / g.lpq), 4)), dim3(256), 0, st, g.kt, 1, g.lpq, g.m_pad,
+    if (data_bf16)
+        hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(divup(g.m_pad / (64 / g.lpq), 4)), dim3(256), 0, st, g.kt, mode, g.lpq, g.m_pad,
                            g.splits, k, m, n, (const uint16_t *)q, (const uint16_t *)r, lists, counts, qnorm,
                            scal, index_base, keys, amb_list);
     else
-        hipLaunchKernelGGL(finalize_kernel<float>, dim3(divup(g.m_pad / (64 / g.lpq), 4)), dim3(256), 0, st, g.kt, 0, g.lpq, g.m_pad,
+        hipLaunchKernelGGL(finalize_kernel<float>, dim3(divup(g.m_pad / (64 / g.lpq), 4)), dim3(256), 0, st, g.kt, mode, g.lpq, g.m_pad,
                            g.splits, k, m, n, (const float *)q, (const float *)r, lists, counts, qnorm, scal,
                            index_base, keys, amb_list);
     NNS_HIP(hipGetLastError());

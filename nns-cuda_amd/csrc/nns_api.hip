@@ -51,6 +51,7 @@ struct nns_index {
     int bf16 = 0;
     bool profile = false;
     bool refs_bad = false;
+    bool mixed = false;            // NNS_FILTER_BF16: fp32 points, bf16 filter operands
 
     // MFMA path, ref side
     FilterGeom geom{};
@@ -106,7 +107,7 @@ static int prep_refs(nns_index *ix, hipStream_t st)
     const FilterGeom &g = ix->geom;
     NNS_HIP(hipMemsetAsync(ix->scal, 0, sizeof(DevScalars), st));
     if (ix->bf16) {
-        NNS_TRY(launch_prep_image_bf16(NNS_BF16_TILE16 ? 1 : 0, ix->k, ix->n, g.n_pad, (const uint16_t *)ix->r_dev, -2.0f, INFINITY,
+        NNS_TRY(launch_prep_image_bf16(NNS_BF16_TILE16 ? 1 : 0, g.kt, ix->k, ix->n, g.n_pad, (const uint16_t *)ix->r_dev, -2.0f, INFINITY,
                                        ix->rimg, ix->rnorm, &ix->scal->ymax2_bits,
                                        &ix->scal->r_maxabs_bits, st));
         return NNS_OK;
@@ -114,7 +115,8 @@ static int prep_refs(nns_index *ix, hipStream_t st)
     NNS_TRY(launch_prep_mean(ix->k, g.kt, ix->n, (const float *)ix->r_dev, ix->mean_ws, ix->mean,
                              &ix->scal->r_maxabs_bits, st));
     NNS_TRY(launch_prep_image(ix->k, g.kt, ix->n, g.n_pad, (const float *)ix->r_dev, ix->mean, -2.0f,
-                              INFINITY, (float *)ix->rimg, ix->rnorm, &ix->scal->ymax2_bits, nullptr, st));
+                              INFINITY, (float *)ix->rimg, ix->rnorm, &ix->scal->ymax2_bits, nullptr, st,
+                              ix->mixed));
     return NNS_OK;
 }
 
@@ -211,13 +213,21 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
         ix->r_dev = ix->r_own;
     }
     ix->profile = (flags & NNS_PROFILE) != 0;
+    if (flags & NNS_FILTER_BF16) {
+        if (bf16) {
+            set_error("NNS_FILTER_BF16 applies to fp32 points (bf16 points already use the bf16 filter)");
+            nns_index_destroy(ix);
+            return NNS_ERR_INVALID;
+        }
+        ix->mixed = true;
+    }
 
     const int kmax = 256;   // deepest tile of the MFMA filter (fp32 and bf16)
     int path = flags & NNS_PATH_MASK;
     // crossover: from k = 8 the MFMA filter (KT = 32 tile) beats 3k VALU ops per pair; bf16 tiles
     // are 256 deep, so they only pay from k = 32
     const int kmin = bf16 ? 32 : 8;
-    if (path == NNS_PATH_AUTO) path = (k >= kmin && k <= kmax) ? NNS_PATH_MFMA : NNS_PATH_EXACT;
+    if (path == NNS_PATH_AUTO) path = (k >= (ix->mixed ? 32 : kmin) && k <= kmax) ? NNS_PATH_MFMA : NNS_PATH_EXACT;
     if (path == NNS_PATH_MFMA && k > kmax) {
         set_error("NNS_PATH_MFMA: k = %d > %d is not tiled yet (use NNS_PATH_AUTO/EXACT)", k, kmax);
         delete ix;
@@ -239,7 +249,7 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
             ix->ev_valid = true;
         }
         if (path == NNS_PATH_MFMA) {
-            if ((rc = filter_plan(k, 1, n, bf16 != 0, &ix->geom)) != NNS_OK) break;
+            if ((rc = filter_plan(k, 1, n, bf16 != 0, &ix->geom, ix->mixed)) != NNS_OK) break;
             const FilterGeom &g = ix->geom;
             size_t ws = 0;
             prep_workspace_bytes(g.kt, &ws);
@@ -311,7 +321,7 @@ static int ensure_query_ws(nns_index *ix, int m)
 {
     FilterGeom g = ix->geom;
     FilterGeom gq{};
-    NNS_TRY(filter_plan(ix->k, m, ix->n, ix->bf16 != 0, &gq));
+    NNS_TRY(filter_plan(ix->k, m, ix->n, ix->bf16 != 0, &gq, ix->mixed));
     ix->geom = gq;   // same kt / n_pad / total_slots; m-dependent grid now filled in
     (void)g;
     if (gq.m_pad > ix->m_cap) {
@@ -411,11 +421,11 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
                   "per-search scalars must be adjacent");
     NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned) + sizeof(int), st));
     if (bf16)
-        NNS_TRY(launch_prep_image_bf16(NNS_BF16_TILE16 ? 1 : 0, ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
+        NNS_TRY(launch_prep_image_bf16(NNS_BF16_TILE16 ? 1 : 0, g.kt, ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
                                        nullptr, &ix->scal->q_maxabs_bits, st));
     else
         NNS_TRY(launch_prep_image(ix->k, g.kt, m, g.m_pad, (const float *)q_dev, ix->mean, 1.0f, 0.0f,
-                                  (float *)ix->qimg, ix->qnorm, nullptr, &ix->scal->q_maxabs_bits, st));
+                                  (float *)ix->qimg, ix->qnorm, nullptr, &ix->scal->q_maxabs_bits, st, ix->mixed));
     if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_QPREP], st);
     NNS_TRY(launch_filter(g, ix->qimg, ix->rimg, ix->rnorm, ix->qnorm, ix->scal, ix->lists, ix->counts, st));
     if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_FILTER], st);

@@ -80,6 +80,7 @@ constexpr int kBlockPts = 32;
 struct FilterGeom {
     int bf16;             // 1: bf16 operands (K4), 0: fp32 operands (K3)
     int lpq;              // lanes (= private candidate lists) per query and split: 2, or 4 with 16x16 tiles
+    int mixed;            // 1: fp32 points through the bf16 filter (NNS_FILTER_BF16); bf16 = 1 then too
     int kt;               // K of the tile (k padded up with zeros)
     int m_pad;            // queries padded to the workgroup's query count
     int n_pad;            // refs padded to a whole ring slot
@@ -110,8 +111,10 @@ struct TauConsts {
     float c0, c1, x2;
 };
 
-__host__ __device__ inline TauConsts tau_consts(int kt, float qnorm2, float ymax2, bool bf16)
+// mode: 0 fp32 operands, 1 bf16 points (operands exact), 2 fp32 points ROUNDED to bf16 operands
+__host__ __device__ inline TauConsts tau_consts(int kt, float qnorm2, float ymax2, int mode)
 {
+    const bool bf16 = mode != 0;
     const double u = 5.9604644775390625e-08;   // 2^-24
     const double X2 = (double)qnorm2 * (1.0 + 4.0 * u);
     const double Y2 = (double)ymax2 * (1.0 + 4.0 * u);
@@ -128,6 +131,14 @@ __host__ __device__ inline TauConsts tau_consts(int kt, float qnorm2, float ymax
         const double gf = 2.0 * (kt + kt / 16 + 2) * u / (1.0 - 2.0 * (kt + kt / 16 + 2) * u);
         e3 = gf * (Y2 + 2.0 * X * Y) + 2.0 * u * Y2;
         e2 = 0.0;                            // no centring on the bf16 path
+        if (mode == 2) {
+            // operands x^ = rn_bf16(x'), y^ = rn_bf16(y') with |x^ - x'| <= 2^-8 |x'| (8-bit significand):
+            // |x^.y^ - x'.y'| <= (2 * 2^-8 + 2^-16) sum |x'_t||y'_t| <= 2^-7 (1 + 2^-9) X Y, doubled by the
+            // factor -2 of the score; plus the centring term of the fp32 path (x' = fl(x - c)), and the
+            // accumulation bound above on the slightly larger rounded magnitudes
+            e3 = e3 * (1.0 + 0x1p-6) + 0x1p-6 * (1.0 + 0x1p-8) * X * Y;
+            e2 = 2.5 * u * (X + Y) * (X + Y);
+        }
     }
     const double c1 = 2.0 * gk / (1.0 - gk) * 1.001;
     const double c0 = (2.0 + c1) * (e3 + e2) * 1.001 + 1e-30;
@@ -185,7 +196,7 @@ int launch_prep_mean(int k, int kt, int n, const float *r, double *partial_ws,
 int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts,
                       const float *mean, float scale, float pad_norm,
                       float *img, float *norms, unsigned *max_norm_bits,
-                      unsigned *maxabs_bits, hipStream_t st);
+                      unsigned *maxabs_bits, hipStream_t st, bool out_bf16 = false);
 
 // bf16 points (raw uint16 bits) -> bf16 tile image [blk][16][64 lanes][8 bf16], value * scale
 // (scale = 1 or -2, exact), fp32 norms of the UNcentred points, max-|v| word
@@ -193,12 +204,12 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts,
 // core.cu:293-306); esz = 4 (fp32) or 2 (bf16 bits)
 int launch_soa_to_aos(int k, int n, const void *src, void *dst, int esz, hipStream_t st);
 // order: 0 = 32x32x16 operands, 1 = 16x16x32 operands (fragment 8 * tile + k-step)
-int launch_prep_image_bf16(int order, int k, int npts, int npts_pad, const uint16_t *pts, float scale,
+int launch_prep_image_bf16(int order, int kt, int k, int npts, int npts_pad, const uint16_t *pts, float scale,
                            float pad_norm, void *img, float *norms, unsigned *max_norm_bits,
                            unsigned *maxabs_bits, hipStream_t st);
 
 // filter_mfma.hip (K3 fp32 / K4 bf16)
-int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g);
+int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed = false);
 int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const float *rnorm,
                   const float *qnorm, const DevScalars *scal, CandEntry *lists, int *counts,
                   hipStream_t st);

@@ -143,7 +143,10 @@ int launch_prep_mean(int k, int kt, int n, const float *r, double *partial_ws, f
 }
 
 // image kernel: one workgroup = one block of 32 points.
-template <int KT>
+// BF = 1 (NNS_FILTER_BF16, fp32 points through the bf16 filter): the same centring and fp32 norms, but
+// the image holds the centred, scaled values ROUNDED to bf16 (RNE) in the 16x16x32 operand order of
+// image_bf16_kernel (order 1).  KT = 256 only.
+template <int KT, int BF = 0>
 __global__ __launch_bounds__(256) void image_kernel(int k, int npts, const float *__restrict__ pts,
                                                     const float *__restrict__ mean, float scale,
                                                     float pad_norm, float *__restrict__ img,
@@ -230,6 +233,26 @@ __global__ __launch_bounds__(256) void image_kernel(int k, int npts, const float
         }
     }
 
+    if constexpr (BF != 0) {
+        static_assert(BF == 0 || KT == 256 || KT == 128, "the bf16 operand image is 128 or 256 deep");
+        // fragment f = NKS * tile + k-step; lane l: point 16 tile + (l & 15), dims 32 ks + 8 (l >> 4) .. + 7
+        constexpr int NKS = KT / 32;
+        uint4 *outb = reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(img) + (size_t)blk * 32 * KT);
+        for (int f = tid; f < 2 * NKS * 64; f += 256) {
+            const int s16 = f >> 6, lane = f & 63;
+            const int i = 16 * (s16 / NKS) + (lane & 15), d0 = 32 * (s16 % NKS) + 8 * (lane >> 4);
+            unsigned w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // scale (+1 / -2) is exact in fp32 and in bf16; ONE rounding to bf16, NaN stays NaN
+                const __bf16 lo = (__bf16)(tile[i * LD + d0 + 2 * e] * scale);
+                const __bf16 hi = (__bf16)(tile[i * LD + d0 + 2 * e + 1] * scale);
+                w[e] = (unsigned)__builtin_bit_cast(unsigned short, lo) |
+                       ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+            }
+            outb[f] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else {
     // write the image: float4 #f of the block = img[b][lane][0..3], lane = 32h + i
     float4 *out = reinterpret_cast<float4 *>(img + (size_t)blk * 32 * KT);
     for (int f = tid; f < (KT / 8) * 64; f += 256) {
@@ -243,6 +266,7 @@ __global__ __launch_bounds__(256) void image_kernel(int k, int npts, const float
         o.w = v.w * scale;
         out[f] = o;
     }
+    }
 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -254,9 +278,23 @@ __global__ __launch_bounds__(256) void image_kernel(int k, int npts, const float
 
 int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, const float *mean,
                       float scale, float pad_norm, float *img, float *norms,
-                      unsigned *max_norm_bits, unsigned *maxabs_bits, hipStream_t st)
+                      unsigned *max_norm_bits, unsigned *maxabs_bits, hipStream_t st, bool out_bf16)
 {
     const int blocks = npts_pad / 32;
+    if (out_bf16) {
+        if (kt != 256 && kt != 128) {
+            set_error("prep: the bf16 operand image is 128 or 256 deep (kt = %d)", kt);
+            return NNS_ERR_UNSUPPORTED;
+        }
+        if (kt == 256)
+            hipLaunchKernelGGL((image_kernel<256, 1>), dim3(blocks), dim3(256), 0, st, k, npts, pts, mean, scale,
+                               pad_norm, img, norms, max_norm_bits, maxabs_bits);
+        else
+            hipLaunchKernelGGL((image_kernel<128, 1>), dim3(blocks), dim3(256), 0, st, k, npts, pts, mean, scale,
+                               pad_norm, img, norms, max_norm_bits, maxabs_bits);
+        NNS_HIP(hipGetLastError());
+        return NNS_OK;
+    }
     switch (kt) {
     case 32:
         hipLaunchKernelGGL(image_kernel<32>, dim3(blocks), dim3(256), 0, st, k, npts, pts, mean,
@@ -286,15 +324,16 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, c
 //
 // order 1 (v_mfma_f32_16x16x32_bf16 operands, the product): a fragment is one 16-point tile t x
 // one k-step ks of 32 dims; lane l holds dims 32 ks + 8 (l >> 4) .. + 7 of point 16 t + (l & 15);
-// the block stores fragment 8 t + ks (the filter walks a ref tile's 8 k-steps in a row; a wave
+// the block stores fragment (KT / 32) t + ks (the filter walks a ref tile's k-steps in a row; a wave
 // keeps all k-steps of its four query tiles in registers).  order 0: the 32x32x16 layout above.
+template <int KT>
 __global__ __launch_bounds__(256) void image_bf16_kernel(int order, int k, int npts, const uint16_t *__restrict__ pts,
                                                          float scale, float pad_norm,
                                                          uint16_t *__restrict__ img, float *__restrict__ norms,
                                                          unsigned *__restrict__ max_norm_bits,
                                                          unsigned *__restrict__ maxabs_bits)
 {
-    constexpr int KT = 256, LD = KT + 8;
+    constexpr int LD = KT + 8, NKS = KT / 32;
     __shared__ __attribute__((aligned(16))) uint16_t tile[32 * LD];
     __shared__ double nrm[32][8];
     const int tid = threadIdx.x;
@@ -356,14 +395,14 @@ __global__ __launch_bounds__(256) void image_bf16_kernel(int order, int k, int n
     }
     // 16-byte fragments: f = s * 64 + lane
     uint4 *out = reinterpret_cast<uint4 *>(img + (size_t)blk * 32 * KT);
-    for (int f = tid; f < 16 * 64; f += 256) {
+    for (int f = tid; f < (KT / 16) * 64; f += 256) {
         const int s = f >> 6, lane = f & 63;
         int i, d0;   // point of the block and first dim of this lane's 8
         if (order == 0) {
             i = lane & 31;
             d0 = 16 * s + 8 * (lane >> 5);
         } else {
-            const int t = s >> 3, ks = s & 7;
+            const int t = s / NKS, ks = s % NKS;
             i = 16 * t + (lane & 15);
             d0 = 32 * ks + 8 * (lane >> 4);
         }
@@ -387,12 +426,20 @@ __global__ __launch_bounds__(256) void image_bf16_kernel(int order, int k, int n
     if ((tid & 63) == 0 && maxabs_bits) max_word(maxabs_bits, mx);
 }
 
-int launch_prep_image_bf16(int order, int k, int npts, int npts_pad, const uint16_t *pts, float scale, float pad_norm,
+int launch_prep_image_bf16(int order, int kt, int k, int npts, int npts_pad, const uint16_t *pts, float scale, float pad_norm,
                            void *img, float *norms, unsigned *max_norm_bits, unsigned *maxabs_bits,
                            hipStream_t st)
 {
-    hipLaunchKernelGGL(image_bf16_kernel, dim3(npts_pad / 32), dim3(256), 0, st, order, k, npts, pts, scale, pad_norm,
-                       (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
+    if (kt == 256)
+        hipLaunchKernelGGL(image_bf16_kernel<256>, dim3(npts_pad / 32), dim3(256), 0, st, order, k, npts, pts, scale,
+                           pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
+    else if (kt == 128 && order == 1)
+        hipLaunchKernelGGL(image_bf16_kernel<128>, dim3(npts_pad / 32), dim3(256), 0, st, order, k, npts, pts, scale,
+                           pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
+    else {
+        set_error("prep: unsupported bf16 tile K %d (order %d)", kt, order);
+        return NNS_ERR_UNSUPPORTED;
+    }
     NNS_HIP(hipGetLastError());
     return NNS_OK;
 }

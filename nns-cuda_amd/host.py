@@ -27,6 +27,7 @@ LIB_PATH = os.environ.get("NNS_LIB_PATH") or os.path.join(_HERE, "libnns_mi355x.
 
 NNS_OK = 0
 NNS_PATH_AUTO, NNS_PATH_EXACT, NNS_PATH_MFMA, NNS_PROFILE, NNS_MULTI_VIRTUAL, NNS_REFS_SOA = 0, 1, 2, 16, 32, 64
+NNS_FILTER_BF16 = 128
 NNS_KEY_NONE = 0x7F80000000000000
 
 _PATHS = {"auto": NNS_PATH_AUTO, "exact": NNS_PATH_EXACT, "mfma": NNS_PATH_MFMA}
@@ -161,7 +162,7 @@ def cudaCall(k: int, m: int, n: int, s_points, r_points) -> np.ndarray:
 
 
 def search(query_points, reference_points, *, return_distances: bool = False, shards: int = 1,
-           path: str = "auto", device: int = 0, refs_soa: bool = False):
+           path: str = "auto", device: int = 0, refs_soa: bool = False, filter_bf16: bool = False):
     """``search(query_points, reference_points)`` — the entry point BASELINE.json names.
 
     Host arrays in, nearest-reference index per query out (and, optionally, V0's
@@ -178,7 +179,8 @@ def search(query_points, reference_points, *, return_distances: bool = False, sh
     dist = np.empty(m, dtype=np.float32) if return_distances else None
     _check(lib.nns_search_f32_ex(k, m, n, q.ctypes.data, r.ctypes.data, idx.ctypes.data,
                                  dist.ctypes.data if dist is not None else None, shards,
-                                 _PATHS[path] | (NNS_REFS_SOA if refs_soa else 0), device), "nns_search_f32_ex")
+                                 _PATHS[path] | (NNS_REFS_SOA if refs_soa else 0)
+                                 | (NNS_FILTER_BF16 if filter_bf16 else 0), device), "nns_search_f32_ex")
     return (idx, dist) if return_distances else idx
 
 
@@ -251,7 +253,7 @@ class Index:
     """One prepared, device-resident shard of reference points (nns_index)."""
 
     def __init__(self, refs, *, index_base: int = 0, path: str = "auto", profile: bool = False, stream=None,
-                 soa: bool = False):
+                 soa: bool = False, filter_bf16: bool = False):
         """refs: [n][k] (or, with soa=True, dimension-major [k][n]: NNS_REFS_SOA) on a HIP device."""
         import torch
         if refs.dtype not in (torch.float32, torch.bfloat16) or refs.dim() != 2 or not refs.is_contiguous() \
@@ -261,7 +263,8 @@ class Index:
         self.refs = refs  # keep alive: the index reads the original values
         self.n, self.k = (refs.shape[1], refs.shape[0]) if soa else refs.shape
         self.device = refs.device.index or 0
-        flags = _PATHS[path] | (NNS_PROFILE if profile else 0) | (NNS_REFS_SOA if soa else 0)
+        flags = _PATHS[path] | (NNS_PROFILE if profile else 0) | (NNS_REFS_SOA if soa else 0) \
+            | (NNS_FILTER_BF16 if filter_bf16 else 0)
         h = ctypes.c_void_p()
         create = lib.nns_index_create_bf16 if self.bf16 else lib.nns_index_create
         _check(create(ctypes.byref(h), self.device, self.k, self.n, refs.data_ptr(),

@@ -666,3 +666,43 @@ def test_bench_multirank_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["n"] == 2 * d["config"]["refs_per_gpu"]
     assert d["verified_vs_unsharded"] is True
     assert d["scaling"] == "weak" and "cpu_baseline" not in d
+
+
+@pytest.mark.parametrize("shape", [(300, 5000, 128), (700, 20001, 200), (1000, 70000, 64), (130, 3000, 33),
+                                   (2049, 777, 256), (65, 40000, 100)])
+def test_bf16_filter_on_fp32_points(pkg, orc, shape):
+    """NNS_FILTER_BF16 (opt-in): fp32 points, filter on the centred points rounded to bf16 with the
+    margin widened by the rounding bound, exact fp32 re-rank.  Indices and distance bits must equal
+    V0's (and therefore the fp32-filter path's) on benign and on adversarial data: exact duplicates,
+    near-duplicates below bf16 resolution (they are indistinguishable to the filter and must all be
+    re-ranked), offset clouds (centring), NaN / INF refs."""
+    m, n, k = shape
+    rng = np.random.default_rng(1100 + k)
+    q = rng.random((m, k), dtype=np.float32)
+    r = rng.random((n, k), dtype=np.float32)
+    r[n // 2:n // 2 + 40] = r[:40]                                   # exact duplicates
+    twins = r[100:140].copy()
+    twins[:, 1] += np.float32(2e-4)                                  # differ below bf16 resolution
+    r[n // 3:n // 3 + 40] = twins
+    q[:30] = r[100:130] + rng.normal(0, 1e-4, (30, k)).astype(np.float32)
+    want_idx, want_dist = orc.v0_search(q, r, threads=8)
+    for shards in (1, 3):
+        idx, dist = pkg.search(q, r, return_distances=True, shards=shards, path="mfma", filter_bf16=True)
+        assert np.array_equal(idx, want_idx), f"shards={shards}"
+        assert np.array_equal(_bits(dist), _bits(want_dist))
+    # offset cloud + specials through the resident index
+    q2, r2 = q + np.float32(500.0), r + np.float32(500.0)
+    r2[7, 3] = np.nan
+    r2[n - 1, 0] = np.inf
+    with np.errstate(all="ignore"):
+        w2 = orc.v0_search(q2, r2, threads=8)
+    ix = pkg.Index(torch.from_numpy(r2).cuda(), filter_bf16=True, path="mfma")
+    idx, dist = ix.search(torch.from_numpy(q2).cuda(), return_distances=True)
+    assert np.array_equal(idx.cpu().numpy(), w2[0]) and np.array_equal(_bits(dist.cpu().numpy()), _bits(w2[1]))
+    ix.close()
+
+
+def test_bf16_filter_flag_is_rejected_for_bf16_points(pkg):
+    q = torch.zeros((64, 64), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(pkg.NNSError):
+        pkg.Index(q, filter_bf16=True)

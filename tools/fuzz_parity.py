@@ -71,6 +71,8 @@ def main():
         if path == "mfma" and k > 256:
             path = "auto"
         shards = int(rng.choice([1, 1, 2, 3]))
+        # opt-in bf16 filter on fp32 points (NNS_FILTER_BF16): same answers required
+        mixed = (not bf16) and 32 <= k <= 256 and path != "exact" and bool(rng.integers(0, 2))
         q, r = make_cloud(rng, m, n, k, fam)
         with np.errstate(all="ignore"):
             if bf16:
@@ -80,13 +82,13 @@ def main():
                                             shards=shards, path=path)
             else:
                 want_idx, want_dist = orc.v0_search(q, r, threads=16)
-                idx, dist = pkg.search(q, r, return_distances=True, shards=shards, path=path)
+                idx, dist = pkg.search(q, r, return_distances=True, shards=shards, path=path, filter_bf16=mixed)
         cases += 1
         ok = np.array_equal(idx, want_idx) and np.array_equal(dist.view(np.uint32), want_dist.view(np.uint32))
         if not ok:
             fails += 1
             bad = np.nonzero(idx != want_idx)[0]
-            print(f"FAIL m={m} n={n} k={k} family={fam} bf16={bf16} path={path} shards={shards}: "
+            print(f"FAIL m={m} n={n} k={k} family={fam} bf16={bf16} mixed={mixed} path={path} shards={shards}: "
                   f"{bad.size} index mismatches (first {bad[:4]}), "
                   f"{int((dist.view(np.uint32) != want_dist.view(np.uint32)).sum())} distance mismatches", flush=True)
         if time.time() - last > 30:
