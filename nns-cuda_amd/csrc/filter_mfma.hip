@@ -170,6 +170,7 @@ struct OpF32T {  // fp32 operands: float4 #b = operands of MFMA k-steps 4b .. 4b
 };
 using OpF32 = OpF32T<16, NNS_F_QB_F32>;      // KT = 128
 using OpF32K32 = OpF32T<4, NNS_F_QB_F32>;    // KT = 32: the mid-range dimensionalities (k = 8 .. 32)
+using OpF32K64 = OpF32T<8, NNS_F_QB_F32>;    // KT = 64: 32 < k <= 64 without padding to 128
 // KT = 256 (128 < k <= 256): the resident operands of ONE query block already take 128 registers,
 // a ring slot holds one 32-ref block (32 KiB), and the ring turns twice as often per MFMA
 using OpF32K256 = OpF32T<32, 1>;
@@ -859,6 +860,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
         else if (k <= 256) kt = 256;
     } else {
         if (k <= 32) kt = 32;          // OpF32K32: 4 fragment steps per block, 8 blocks per slot
+        else if (k <= 64) kt = 64;     // OpF32K64: 8 steps per block, 4 blocks per slot
         else if (k <= 128) kt = 128;
         else if (k <= 256) kt = 256;   // OpF32K256: 32 fragment steps per block, 1 block per slot
     }
@@ -950,6 +952,7 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
     if (clk && atoi(clk)) NNS_HIP(hipMalloc(&a.stamps, nwg * 4 * sizeof(unsigned long long)));
     const int rc = g.bf16 ? (g.kt == 128 ? launch_filter_t<OpBF16K128>(g, a, st) : launch_filter_t<OpBF16Active>(g, a, st))
                           : (g.kt == 32    ? launch_filter_t<OpF32K32>(g, a, st)
+                             : g.kt == 64  ? launch_filter_t<OpF32K64>(g, a, st)
                              : g.kt == 256 ? launch_filter_t<OpF32K256>(g, a, st)
                                            : launch_filter_t<OpF32>(g, a, st));
     if (a.stamps) {   // diagnostic: synchronous read-out, median clock over workgroups

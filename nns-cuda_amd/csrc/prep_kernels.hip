@@ -300,6 +300,10 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, c
         hipLaunchKernelGGL(image_kernel<32>, dim3(blocks), dim3(256), 0, st, k, npts, pts, mean,
                            scale, pad_norm, img, norms, max_norm_bits, maxabs_bits);
         break;
+    case 64:
+        hipLaunchKernelGGL(image_kernel<64>, dim3(blocks), dim3(256), 0, st, k, npts, pts, mean,
+                           scale, pad_norm, img, norms, max_norm_bits, maxabs_bits);
+        break;
     case 128:
         hipLaunchKernelGGL(image_kernel<128>, dim3(blocks), dim3(256), 0, st, k, npts, pts, mean,
                            scale, pad_norm, img, norms, max_norm_bits, maxabs_bits);

@@ -706,3 +706,19 @@ def test_bf16_filter_flag_is_rejected_for_bf16_points(pkg):
     q = torch.zeros((64, 64), dtype=torch.bfloat16, device="cuda")
     with pytest.raises(pkg.NNSError):
         pkg.Index(q, filter_bf16=True)
+
+
+@pytest.mark.parametrize("shape", [(300, 5000, 64), (700, 20001, 33), (2049, 777, 50), (1000, 70000, 64)])
+def test_filter_k64_tile_shapes(pkg, orc, shape):
+    """32 < k <= 64 runs the 64-deep fp32 MFMA tile (4 image blocks = 128 refs per ring slot)."""
+    m, n, k = shape
+    rng = np.random.default_rng(640 + k + m)
+    q = rng.random((m, k), dtype=np.float32)
+    r = rng.random((n, k), dtype=np.float32)
+    r[n // 2:n // 2 + 30] = r[:30]
+    _check(pkg, orc, q, r, paths=("mfma", "auto"), shards=(1, 3))
+    ix = pkg.Index(torch.from_numpy(r).cuda())
+    ix.search(torch.from_numpy(q).cuda())
+    st = ix.stats()
+    assert st["path"] == 2 and st["k_tile"] == 64, st
+    ix.close()

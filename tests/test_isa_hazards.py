@@ -53,7 +53,7 @@ def test_filter_kernels_have_no_mfma_read_hazards():
                 cur = None
                 continue
             cur.append((i, l))
-    assert len(kernels) == 5, list(kernels)   # fp32 KT = 32 / 128 / 256, bf16 KT = 128 / 256
+    assert len(kernels) == 6, list(kernels)   # fp32 KT = 32 / 64 / 128 / 256, bf16 KT = 128 / 256
     for name, lines in kernels.items():
         assert sum("v_mfma" in l for _, l in lines) >= 128, name
         assert chk.check_kernel(name, lines) == [], name
