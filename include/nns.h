@@ -64,7 +64,7 @@ enum {
 
 /* path selection flags (nns_index_create / nns_search_f32_ex) */
 enum {
-    NNS_PATH_AUTO = 0,   /* MFMA filter for 8 <= k <= 256 (bf16: 32..256) and >= 64 queries, exact kernels otherwise */
+    NNS_PATH_AUTO = 0,   /* MFMA filter for 8 <= k <= 256 (bf16 points: 32..512) and >= 64 queries, exact kernels otherwise */
     NNS_PATH_EXACT = 1,  /* exact per-pair kernels only (V1..V9 arithmetic re-expressed) */
     NNS_PATH_MFMA = 2,   /* -2*Q*R^T MFMA filter + exact re-rank (k padded to the tile K) */
     NNS_PATH_MASK = 3,

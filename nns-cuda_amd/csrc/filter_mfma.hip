@@ -244,12 +244,13 @@ using OpBF16K128 = OpBF16T<8>;    // KT = 128: k <= 128 without padding to 256 (
 
 // OpBF16T32: v_mfma_f32_32x32x16_bf16 (the first version; kept for A/B builds with
 // -DNNS_BF16_TILE32): 16 bytes = 8 bf16 = one operand, lane = query, 16 refs per lane.
-struct OpBF16T32 {
-    static constexpr int kSPB = 16;
+template <int SPB_, int QB_>
+struct OpBF16T32T {
+    static constexpr int kSPB = SPB_;         // fragment steps (16 dims each) per 32-ref block
     static constexpr bool kTile16 = false;
     static constexpr bool kLag = true;
     using Acc = AccSet;
-    static constexpr int kQB = NNS_F_QB_BF16;
+    static constexpr int kQB = QB_;
     static constexpr int kNW = NNS_F_NW_BF16;
     static constexpr int kPrefetch = NNS_F_PF_BF16;   // one MFMA (32 cycles) per fragment and query block
     __device__ static __forceinline__ f32x16 mma(const float4 &a, const float4 &b, f32x16 acc)
@@ -258,6 +259,10 @@ struct OpBF16T32 {
                                                        __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
 };
+using OpBF16T32 = OpBF16T32T<16, NNS_F_QB_BF16>;   // KT = 256
+// KT = 512 (256 < k <= 512): the 32x32x16 form with ONE query block per wave (its resident operands are
+// 128 registers) and one 32-ref block per ring slot — the bf16 twin of OpF32K256
+using OpBF16K512 = OpBF16T32T<32, 1>;
 #if NNS_BF16_TILE16
 using OpBF16Active = OpBF16;
 #else
@@ -858,6 +863,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
     if (bf16) {
         if (k <= 128) kt = 128;        // OpBF16K128: 4 k-steps per 16-ref tile, 4 blocks per slot
         else if (k <= 256) kt = 256;
+        else if (k <= 512 && !mixed) kt = 512;   // OpBF16K512 (bf16 points only)
     } else {
         if (k <= 32) kt = 32;          // OpF32K32: 4 fragment steps per block, 8 blocks per slot
         else if (k <= 64) kt = 64;     // OpF32K64: 8 steps per block, 4 blocks per slot
@@ -865,15 +871,15 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
         else if (k <= 256) kt = 256;   // OpF32K256: 32 fragment steps per block, 1 block per slot
     }
     if (!kt) {
-        set_error("MFMA filter: k = %d exceeds the tile depth (256)", k);
+        set_error("MFMA filter: k = %d exceeds the deepest tile (fp32 points: 256, bf16 points: 512)", k);
         return NNS_ERR_UNSUPPORTED;
     }
     g->bf16 = bf16 ? 1 : 0;
     g->mixed = mixed ? 1 : 0;
     g->kt = kt;
-    g->lpq = (bf16 && OpBF16Active::kTile16) ? 4 : 2;
+    g->lpq = (bf16 && kt != 512 && OpBF16Active::kTile16) ? 4 : 2;
     // queries per workgroup
-    const int qw = 32 * (bf16 ? OpBF16Active::kQB * OpBF16Active::kNW
+    const int qw = 32 * (bf16 ? (kt == 512 ? OpBF16K512::kQB * OpBF16K512::kNW : OpBF16Active::kQB * OpBF16Active::kNW)
                               : (kt == 256 ? OpF32K256::kQB * OpF32K256::kNW : OpF32::kQB * OpF32::kNW));
     g->m_pad = divup(m, qw) * qw;
     // refs per ring slot (32 fragment steps of 8 fp32 / 16 bf16 dims)
@@ -950,7 +956,9 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
     const char *clk = getenv("NNS_FILTER_CLOCK");
     const size_t nwg = (size_t)g.qgroups * g.splits;
     if (clk && atoi(clk)) NNS_HIP(hipMalloc(&a.stamps, nwg * 4 * sizeof(unsigned long long)));
-    const int rc = g.bf16 ? (g.kt == 128 ? launch_filter_t<OpBF16K128>(g, a, st) : launch_filter_t<OpBF16Active>(g, a, st))
+    const int rc = g.bf16 ? (g.kt == 128   ? launch_filter_t<OpBF16K128>(g, a, st)
+                             : g.kt == 512 ? launch_filter_t<OpBF16K512>(g, a, st)
+                                           : launch_filter_t<OpBF16Active>(g, a, st))
                           : (g.kt == 32    ? launch_filter_t<OpF32K32>(g, a, st)
                              : g.kt == 64  ? launch_filter_t<OpF32K64>(g, a, st)
                              : g.kt == 256 ? launch_filter_t<OpF32K256>(g, a, st)

@@ -31,7 +31,11 @@ using namespace nns;
 
 // one point of a tile image: 512 bytes (128 fp32 dims or 256 bf16 dims; the 32-deep fp32 tile is
 // allocated at the same size), 1 KiB for the 256-deep fp32 tile
-static size_t img_row_bytes(const FilterGeom &g) { return (!g.bf16 && g.kt > 128) ? (size_t)g.kt * 4 : 512; }
+static size_t img_row_bytes(const FilterGeom &g)
+{
+    const size_t b = (size_t)g.kt * (g.bf16 ? 2 : 4);
+    return b > 512 ? b : 512;
+}
 // below this many queries the AUTO path skips the MFMA filter (and, in the whole-call
 // entry points, its ref pre-pass too)
 static const int kTinyM = 64;
@@ -107,7 +111,7 @@ static int prep_refs(nns_index *ix, hipStream_t st)
     const FilterGeom &g = ix->geom;
     NNS_HIP(hipMemsetAsync(ix->scal, 0, sizeof(DevScalars), st));
     if (ix->bf16) {
-        NNS_TRY(launch_prep_image_bf16(NNS_BF16_TILE16 ? 1 : 0, g.kt, ix->k, ix->n, g.n_pad, (const uint16_t *)ix->r_dev, -2.0f, INFINITY,
+        NNS_TRY(launch_prep_image_bf16((NNS_BF16_TILE16 && g.kt != 512) ? 1 : 0, g.kt, ix->k, ix->n, g.n_pad, (const uint16_t *)ix->r_dev, -2.0f, INFINITY,
                                        ix->rimg, ix->rnorm, &ix->scal->ymax2_bits,
                                        &ix->scal->r_maxabs_bits, st));
         return NNS_OK;
@@ -222,7 +226,7 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
         ix->mixed = true;
     }
 
-    const int kmax = 256;   // deepest tile of the MFMA filter (fp32 and bf16)
+    const int kmax = (bf16 && !(flags & NNS_FILTER_BF16)) ? 512 : 256;   // deepest tile of the MFMA filter
     int path = flags & NNS_PATH_MASK;
     // crossover: from k = 8 the MFMA filter (KT = 32 tile) beats 3k VALU ops per pair; bf16 tiles
     // are 256 deep, so they only pay from k = 32
@@ -421,7 +425,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
                   "per-search scalars must be adjacent");
     NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned) + sizeof(int), st));
     if (bf16)
-        NNS_TRY(launch_prep_image_bf16(NNS_BF16_TILE16 ? 1 : 0, g.kt, ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
+        NNS_TRY(launch_prep_image_bf16((NNS_BF16_TILE16 && g.kt != 512) ? 1 : 0, g.kt, ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
                                        nullptr, &ix->scal->q_maxabs_bits, st));
     else
         NNS_TRY(launch_prep_image(ix->k, g.kt, m, g.m_pad, (const float *)q_dev, ix->mean, 1.0f, 0.0f,

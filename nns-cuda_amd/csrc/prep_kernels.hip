@@ -437,6 +437,9 @@ int launch_prep_image_bf16(int order, int kt, int k, int npts, int npts_pad, con
     if (kt == 256)
         hipLaunchKernelGGL(image_bf16_kernel<256>, dim3(npts_pad / 32), dim3(256), 0, st, order, k, npts, pts, scale,
                            pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
+    else if (kt == 512 && order == 0)
+        hipLaunchKernelGGL(image_bf16_kernel<512>, dim3(npts_pad / 32), dim3(256), 0, st, order, k, npts, pts, scale,
+                           pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
     else if (kt == 128 && order == 1)
         hipLaunchKernelGGL(image_bf16_kernel<128>, dim3(npts_pad / 32), dim3(256), 0, st, order, k, npts, pts, scale,
                            pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);

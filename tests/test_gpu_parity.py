@@ -307,7 +307,7 @@ def _check_bf16(pkg, orc, q, r, paths=("auto",), shards=(1,)):
     with np.errstate(all="ignore"):
         want_idx, want_dist = orc.v0_search(qw, rw, threads=8)
     for path in paths:
-        if path == "mfma" and q.shape[1] > 256:
+        if path == "mfma" and q.shape[1] > 512:
             continue
         for s in shards:
             idx, dist = pkg.search_bf16(qb, rb, return_distances=True, shards=s, path=path)
@@ -721,4 +721,21 @@ def test_filter_k64_tile_shapes(pkg, orc, shape):
     ix.search(torch.from_numpy(q).cuda())
     st = ix.stats()
     assert st["path"] == 2 and st["k_tile"] == 64, st
+    ix.close()
+
+
+@pytest.mark.parametrize("shape", [(300, 5000, 512), (700, 20001, 300), (130, 3000, 400), (2049, 777, 257)])
+def test_bf16_k512_tile_shapes(pkg, orc, shape):
+    """bf16 points with 256 < k <= 512: the 512-deep tile (v_mfma_f32_32x32x16_bf16, one query block per
+    wave, one 32-ref block per ring slot), forced and under AUTO, whole and sharded."""
+    m, n, k = shape
+    rng = np.random.default_rng(5120 + k)
+    q = rng.random((m, k), dtype=np.float32)
+    r = rng.random((n, k), dtype=np.float32)
+    r[n // 2:n // 2 + 30] = r[:30]
+    _check_bf16(pkg, orc, q, r, paths=("mfma", "auto"), shards=(1, 3))
+    ix = pkg.Index(torch.from_numpy(orc.round_bf16(r)).cuda().to(torch.bfloat16))
+    ix.search(torch.from_numpy(orc.round_bf16(q)).cuda().to(torch.bfloat16))
+    st = ix.stats()
+    assert st["path"] == 2 and st["k_tile"] == 512, st
     ix.close()
