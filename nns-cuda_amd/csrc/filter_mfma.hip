@@ -863,7 +863,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
     if (bf16) {
         if (k <= 128) kt = 128;        // OpBF16K128: 4 k-steps per 16-ref tile, 4 blocks per slot
         else if (k <= 256) kt = 256;
-        else if (k <= 512 && !mixed) kt = 512;   // OpBF16K512 (bf16 points only)
+        else if (k <= 512) kt = 512;   // OpBF16K512
     } else {
         if (k <= 32) kt = 32;          // OpF32K32: 4 fragment steps per block, 8 blocks per slot
         else if (k <= 64) kt = 64;     // OpF32K64: 8 steps per block, 4 blocks per slot
@@ -871,7 +871,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
         else if (k <= 256) kt = 256;   // OpF32K256: 32 fragment steps per block, 1 block per slot
     }
     if (!kt) {
-        set_error("MFMA filter: k = %d exceeds the deepest tile (fp32 points: 256, bf16 points: 512)", k);
+        set_error("MFMA filter: k = %d exceeds the deepest tile (fp32 operands: 256, bf16 operands: 512)", k);
         return NNS_ERR_UNSUPPORTED;
     }
     g->bf16 = bf16 ? 1 : 0;

@@ -226,7 +226,10 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
         ix->mixed = true;
     }
 
-    const int kmax = (bf16 && !(flags & NNS_FILTER_BF16)) ? 512 : 256;   // deepest tile of the MFMA filter
+    // fp32 points beyond the deepest fp32 tile (256): AUTO takes the bf16-operand filter (512 deep) — the
+    // re-rank makes the result bits identical, and the alternative is the VALU scan
+    if ((flags & NNS_PATH_MASK) == NNS_PATH_AUTO && !bf16 && k > 256 && k <= 512) ix->mixed = true;
+    const int kmax = (bf16 || ix->mixed) ? 512 : 256;   // deepest tile of the MFMA filter
     int path = flags & NNS_PATH_MASK;
     // crossover: from k = 8 the MFMA filter (KT = 32 tile) beats 3k VALU ops per pair; bf16 tiles
     // are 256 deep, so they only pay from k = 32

@@ -276,17 +276,87 @@ __global__ __launch_bounds__(256) void image_kernel(int k, int npts, const float
     if ((tid & 63) == 0 && maxabs_bits) max_word(maxabs_bits, mx);
 }
 
+// NNS_FILTER_BF16 at KT = 512 (fp32 points, 256 < k <= 512; operands in the 32x32x16 order 0 of
+// image_bf16_kernel): the fp32 tile of image_kernel would not fit the 64 KiB of static LDS, so
+// each thread centres, squares (fp64) and rounds a 64-dim run of one point on the fly and only
+// the bf16 values are staged.  Same values as image_kernel<KT, 1> would produce.
+__global__ __launch_bounds__(256) void image_mixed512_kernel(int k, int npts, const float *__restrict__ pts,
+                                                             const float *__restrict__ mean, float scale,
+                                                             float pad_norm, uint16_t *__restrict__ img,
+                                                             float *__restrict__ norms,
+                                                             unsigned *__restrict__ max_norm_bits,
+                                                             unsigned *__restrict__ maxabs_bits)
+{
+    constexpr int KT = 512, LD = KT + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t tile[32 * LD];
+    __shared__ double nrm[32][8];
+    const int tid = threadIdx.x;
+    const int blk = blockIdx.x;
+    const int p0 = blk * 32;
+    const int i = tid >> 3, part = tid & 7;   // 8 threads per point, 64 consecutive dims each
+    const bool live = p0 + i < npts;
+    const float *row = pts + (size_t)(p0 + i) * k;
+    unsigned mx = 0;
+    double acc = 0.0;
+    for (int t = part * 64; t < part * 64 + 64; ++t) {
+        float c = 0.0f;
+        if (live && t < k) {
+            const float v = row[t];
+            const unsigned b = __float_as_uint(v) & 0x7FFFFFFFu;
+            mx = b > mx ? b : mx;
+            c = __fsub_rn(v, mean[t]);   // ONE rounding: x' = fl(x - c)
+        }
+        acc += (double)c * (double)c;
+        // scale (+1 / -2) is exact; ONE rounding to bf16 (RNE), NaN stays NaN
+        tile[i * LD + t] = __builtin_bit_cast(unsigned short, (__bf16)(c * scale));
+    }
+    nrm[i][part] = acc;
+    __syncthreads();
+    if (tid < 32) {
+        double a2 = 0.0;
+        for (int p = 0; p < 8; ++p) a2 += nrm[tid][p];   // fixed order
+        float nv = (float)a2;
+        unsigned nb = 0;
+        if (p0 + tid >= npts) nv = pad_norm;             // padding never wins (refs: +INF)
+        else nb = __float_as_uint(nv);
+        norms[p0 + tid] = nv;
+        if (max_norm_bits) {
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {
+                const unsigned o = __shfl_xor(nb, off, 64);
+                nb = o > nb ? o : nb;
+            }
+            if (tid == 0) max_word(max_norm_bits, nb);
+        }
+    }
+    // 16-byte fragments of the 32x32x16 operand order: f = s * 64 + lane, lane = 32 h + i
+    uint4 *out = reinterpret_cast<uint4 *>(img + (size_t)blk * 32 * KT);
+    for (int f = tid; f < (KT / 16) * 64; f += 256) {
+        const int s16 = f >> 6, lane = f & 63;
+        out[f] = *reinterpret_cast<const uint4 *>(&tile[(lane & 31) * LD + 16 * s16 + 8 * (lane >> 5)]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    if ((tid & 63) == 0 && maxabs_bits) max_word(maxabs_bits, mx);
+}
+
 int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, const float *mean,
                       float scale, float pad_norm, float *img, float *norms,
                       unsigned *max_norm_bits, unsigned *maxabs_bits, hipStream_t st, bool out_bf16)
 {
     const int blocks = npts_pad / 32;
     if (out_bf16) {
-        if (kt != 256 && kt != 128) {
-            set_error("prep: the bf16 operand image is 128 or 256 deep (kt = %d)", kt);
+        if (kt != 512 && kt != 256 && kt != 128) {
+            set_error("prep: the bf16 operand image is 128, 256 or 512 deep (kt = %d)", kt);
             return NNS_ERR_UNSUPPORTED;
         }
-        if (kt == 256)
+        if (kt == 512)
+            hipLaunchKernelGGL(image_mixed512_kernel, dim3(blocks), dim3(256), 0, st, k, npts, pts, mean, scale,
+                               pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
+        else if (kt == 256)
             hipLaunchKernelGGL((image_kernel<256, 1>), dim3(blocks), dim3(256), 0, st, k, npts, pts, mean, scale,
                                pad_norm, img, norms, max_norm_bits, maxabs_bits);
         else

@@ -739,3 +739,30 @@ def test_bf16_k512_tile_shapes(pkg, orc, shape):
     st = ix.stats()
     assert st["path"] == 2 and st["k_tile"] == 512, st
     ix.close()
+
+
+@pytest.mark.parametrize("shape", [(300, 5000, 512), (700, 20001, 300), (130, 3000, 400), (1100, 9000, 257)])
+def test_fp32_points_k512_bf16_operand_tile(pkg, orc, shape):
+    """fp32 points with 256 < k <= 512: no fp32 tile is that deep, so AUTO runs the bf16-operand filter
+    (512-deep tile, rounding-widened margin) + the exact fp32 re-rank.  V0's bits, whole and sharded,
+    also when forced with the flag; near-duplicates below bf16 resolution must all be re-ranked."""
+    m, n, k = shape
+    rng = np.random.default_rng(7000 + k)
+    q = rng.random((m, k), dtype=np.float32)
+    r = rng.random((n, k), dtype=np.float32)
+    r[n // 2:n // 2 + 30] = r[:30]
+    tw = r[60:90].copy()
+    tw[:, 5] += np.float32(3e-4)
+    r[n // 3:n // 3 + 30] = tw
+    q[:25] = r[60:85] + rng.normal(0, 1e-4, (25, k)).astype(np.float32)
+    want_idx, want_dist = orc.v0_search(q, r, threads=8)
+    for kw in ({"path": "auto"}, {"path": "mfma", "filter_bf16": True}):
+        for shards in (1, 3):
+            idx, dist = pkg.search(q, r, return_distances=True, shards=shards, **kw)
+            assert np.array_equal(idx, want_idx), (kw, shards)
+            assert np.array_equal(_bits(dist), _bits(want_dist))
+    ix = pkg.Index(torch.from_numpy(r).cuda())
+    ix.search(torch.from_numpy(q).cuda())
+    st = ix.stats()
+    assert st["path"] == 2 and st["k_tile"] == 512, st
+    ix.close()
