@@ -211,7 +211,7 @@ const char *nns_last_error(void); /* thread-local detail of the last failure */
 int nns_version(void);            /* major * 1000 + minor */
 /* Explicit replacement for the reference's hidden WarmUP static (ten V9 calls before main(),
  * core.cu:1900-1933): runs one tiny search through every kernel family (exact lane-per-query and
- * lane-per-ref, the 32 / 128 / 256-deep fp32 MFMA filters, the bf16 filter) on `device`, so that
+ * lane-per-ref, every fp32 and bf16 tile depth of the MFMA filter) on `device`, so that
  * code-object loading, the filter's LDS opt-in and the first pool allocations are paid here and
  * not inside a timed call.  Optional: every entry point works without it. */
 int nns_warmup(int device);

@@ -693,10 +693,12 @@ int nns_search_bf16_ex(int k, int m, int n, const uint16_t *s_points, const uint
 int nns_warmup(int device)
 {
     NNS_TRY(ensure_device_ok(device));
-    // (k, m, n, bf16): K1a, K1b, the three fp32 tile depths, the bf16 filter
-    static const int shapes[][4] = {{3, 64, 512, 0},  {16, 1, 512, 0},   {16, 64, 512, 0},
-                                    {64, 64, 512, 0}, {200, 64, 512, 0}, {64, 64, 512, 1}};
-    const int kmax = 200, mmax = 64, nmax = 512;
+    // (k, m, n, bf16): K1a, K1b, the fp32 tile depths 32 / 64 / 128 / 256, the bf16-operand tile for fp32
+    // points (512), the bf16 tiles 128 / 256 / 512
+    static const int shapes[][4] = {{3, 64, 512, 0},   {16, 1, 512, 0},   {16, 64, 512, 0},  {40, 64, 512, 0},
+                                    {100, 64, 512, 0}, {200, 64, 512, 0}, {300, 64, 512, 0}, {64, 64, 512, 1},
+                                    {200, 64, 512, 1}, {300, 64, 512, 1}};
+    const int kmax = 300, mmax = 64, nmax = 512;
     float *q = (float *)malloc(sizeof(float) * kmax * mmax), *r = (float *)malloc(sizeof(float) * kmax * nmax);
     int *idx = (int *)malloc(sizeof(int) * mmax);
     if (!q || !r || !idx) {
