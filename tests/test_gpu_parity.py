@@ -766,3 +766,52 @@ def test_fp32_points_k512_bf16_operand_tile(pkg, orc, shape):
     st = ix.stats()
     assert st["path"] == 2 and st["k_tile"] == 512, st
     ix.close()
+
+
+def test_whole_call_entry_points_are_reentrant(pkg, orc):
+    """the whole-call entry points are re-entrant.  Four host threads search
+    different shapes concurrently (ctypes drops the GIL; the workspace pool is shared and locked):
+    every result must be V0's."""
+    import threading
+    rng = np.random.default_rng(4242)
+    jobs = []
+    for (m, n, k) in [(300, 9000, 128), (1000, 5000, 16), (200, 30000, 3), (129, 7000, 200)]:
+        q = rng.random((m, k), dtype=np.float32)
+        r = rng.random((n, k), dtype=np.float32)
+        jobs.append((q, r, orc.v0_search(q, r, threads=4)[0]))
+    errors = []
+
+    def worker(q, r, want):
+        try:
+            for _ in range(12):
+                if not np.array_equal(pkg.search(q, r), want):
+                    errors.append("mismatch")
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+
+
+def test_pool_can_be_disabled():
+    """NNS_POOL_BYTES=0: nothing is parked (every workspace goes back to the runtime on return, like
+    the reference's per-call cudaFree), results unchanged."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, sys; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as g\n"
+        "pkg, orc = g.load_package(), g.load_oracle()\n"
+        "rng = np.random.default_rng(1); q = rng.random((200, 64), dtype=np.float32); r = rng.random((5000, 64), dtype=np.float32)\n"
+        "want = orc.v0_search(q, r)[0]\n"
+        "for _ in range(3): assert np.array_equal(pkg.search(q, r), want)\n"
+        "assert pkg.trim() == 0\n"
+        "print('ok')\n" % root)
+    env = dict(os.environ, NNS_POOL_BYTES="0")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
