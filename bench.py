@@ -97,6 +97,16 @@ def cpu_baseline(orc, q_h, r_dev, idx_gpu, target_s=12.0):
         t2 = time.perf_counter() - t0
         out["all_cores"] = {"value": s2 * n / t2, "cores": cores, "kind": "port",
                             "matches_gpu_indices": bool(np.array_equal(idx2, idx_gpu[:s2]))}
+    # low-dimensional workloads: the reference's other working algorithm family (V10's CPU k-d
+    # tree, core.cu:1060-1163, which itself bails out above 16 dimensions) as a second comparator;
+    # oracle/kdtree.c is exact with V0's semantics (equivalent pairs/s = m * n / t, build included)
+    if q_h.shape[1] <= 16 and np.isfinite(r_h).all() and np.isfinite(q_h).all():
+        t0 = time.perf_counter()
+        idx3, _ = orc.kdtree_search(q_h, r_h, threads=cores)
+        t3 = time.perf_counter() - t0
+        out["kdtree"] = {"value": q_h.shape[0] * n / t3, "unit": "pairs/s (equivalent: m*n / wall time incl. build)",
+                         "cores": cores, "kind": "port", "queries": int(q_h.shape[0]), "seconds": t3,
+                         "matches_gpu_indices": bool(np.array_equal(idx3, idx_gpu[:q_h.shape[0]]))}
     return out
 
 

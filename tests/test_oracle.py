@@ -121,3 +121,24 @@ def test_bf16_rounding(orc):
     assert (y.view(np.uint32) & 0xFFFF == 0).all()
     assert y[0] == 1.0 and y[1] == 1.0 and y[2] == np.float32(1.0078125)   # ties-to-even, round up
     assert np.isnan(orc.round_bf16(np.array([np.nan], np.float32))[0])
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 8, 16])
+def test_kdtree_comparator_equals_v0(k):
+    """oracle/kdtree.c (the reference's V10 family as an additional CPU comparator): the same indices
+    and distance bits as V0 on random, clustered and duplicate-heavy clouds, ties included."""
+    import __graft_entry__ as graft
+    orc = graft.load_oracle()
+    rng = np.random.default_rng(100 + k)
+    for m, n in ((300, 5000), (64, 37), (1000, 20000)):
+        q = rng.random((m, k), dtype=np.float32)
+        r = rng.random((n, k), dtype=np.float32)
+        r[n // 2:n // 2 + n // 10] = r[:n // 10]                      # exact duplicates: lowest index wins
+        q[:m // 4] = r[rng.integers(0, n, m // 4)]                   # exact hits (distance +0, several refs tie)
+        if k >= 2:                                                   # a lattice: many equidistant refs
+            r[-200:] = np.round(r[-200:] * 4) / 4
+            q[-50:] = np.round(q[-50:] * 4) / 4 + np.float32(0.125)
+        want_idx, want_dist = orc.v0_search(q, r, threads=4)
+        got_idx, got_dist = orc.kdtree_search(q, r, threads=4)
+        assert np.array_equal(got_idx, want_idx)
+        assert np.array_equal(got_dist.view(np.uint32), want_dist.view(np.uint32))
