@@ -358,19 +358,16 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             asm volatile("" : "+v"(bq[st][b].x), "+v"(bq[st][b].y), "+v"(bq[st][b].z), "+v"(bq[st][b].w));
         asm volatile("" : "+v"(tc[st].c0), "+v"(tc[st].c1), "+v"(tc[st].x2));
     }
-    // 16x16 tiles carry four states per lane: their tau constants live in LDS behind the ring
-    // (2 KiB per wave, read only on the slow path) instead of 12 more registers; c1 depends on the
-    // tile depth alone and is wave-uniform
+    // The tau constants of the lane's states live in LDS behind the ring (2 KiB per wave, read only on
+    // the slow path) instead of 3 registers per state; c1 depends on the tile depth alone and is
+    // wave-uniform
     float *tcl = reinterpret_cast<float *>(smem + F_LDS_BYTES) + wave * 512 + lane;
-    float c1u = 0.0f;
-    if constexpr (T16) {
 #pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            tcl[(2 * st) * 64] = tc[st].c0;
-            tcl[(2 * st + 1) * 64] = tc[st].x2;
-        }
-        c1u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tc[0].c1)));
+    for (int st = 0; st < NS; ++st) {
+        tcl[(2 * st) * 64] = tc[st].c0;
+        tcl[(2 * st + 1) * 64] = tc[st].x2;
     }
+    const float c1u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tc[0].c1)));
 
     unsigned long long st_t0 = 0, st_r0 = 0;
     if (a.stamps) {   // diagnostic launches only: in-kernel clock = d(memtime) / d(memrealtime) * 100 MHz
@@ -404,7 +401,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     };
 
     // ---- per-lane record state ---------------------------------------------------------
-    float m1[NS], thr[NS];
+    float thr[NS];
     int cnt[NS];
     // candidate lists are stored [split][state unit][entry][lane] (unit = the 64 lanes' lists of
     // one query block / query tile) so that both the appends of a wave and K5's per-query reads
@@ -414,7 +411,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     CandEntry *const list0 = a.lists + lblk0 * (kCandCap * 64) + lane;
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
-        m1[st] = thr[st] = __builtin_inff();
+        thr[st] = __builtin_inff();
         cnt[st] = 0;
         list[st] = list0 + st * (kCandCap * 64);
     }
@@ -456,6 +453,21 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         else nseed1 = f32x4{nv.x, nv.y, nv.z, nv.w};
     };
     // one finished score x of ref j (slow path): append to the state's candidate ring, tighten
+    // Slow path, step 1: tighten the lane's threshold with the minimum tmin of the scores about to be
+    // examined.  Doing this FIRST is what keeps the slow path short: every ref within tau of the
+    // FINAL minimum is below every threshold the lane ever holds (thresholds only shrink), so
+    // appending against the already-tightened threshold still collects all of them, while a run of
+    // descending scores no longer appends (and stores) each one.
+    auto tighten = [&](auto st_c, float tmin) __attribute__((always_inline)) {
+        constexpr int st = decltype(st_c)::value;
+        // x -> x + 1.002 tau(x) is monotone, so the threshold of the running minimum is the minimum
+        // of the thresholds: no separate running-minimum register.  (1.002: a hair wider than K5's
+        // own tau, so that the lists are supersets of what K5 needs.)
+        const float d = tmin + tcl[(2 * st + 1) * 64];
+        const float tn = tmin + (tcl[(2 * st) * 64] + c1u * (d > 0.0f ? d : 0.0f)) * 1.002f;
+        thr[st] = tn < thr[st] ? tn : thr[st];
+    };
+    // Slow path, step 2: one finished score x of ref j: append to the state's candidate ring
     auto record = [&](auto st_c, float x, int j) __attribute__((always_inline)) {
         constexpr int st = decltype(st_c)::value;
         if (x <= thr[st] && x < __builtin_inff()) {
@@ -471,16 +483,6 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             e.j = j;
             lst[pos * 64] = e;
             ++cnt[st];
-            if constexpr (T16) {
-                // x -> x + 1.002 tau(x) is monotone, so the threshold of the running minimum is
-                // the minimum of the thresholds: no separate m1 register
-                const float d = x + tcl[(2 * st + 1) * 64];
-                const float tn = x + (tcl[(2 * st) * 64] + c1u * (d > 0.0f ? d : 0.0f)) * 1.002f;
-                thr[st] = tn < thr[st] ? tn : thr[st];
-            } else if (x < m1[st]) {
-                m1[st] = x;
-                thr[st] = x + tau_of(tc[st], x) * 1.002f;   // a hair wider than K5's own tau
-            }
         }
     };
     // minimum of the finished scores of one ref block for lane state st
@@ -505,6 +507,9 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // slow path of one state: every score of the block against the lane's threshold
     auto record_all = [&](const typename OP::Acc &acc, int blk_global, auto st_c) __attribute__((always_inline)) {
         constexpr int st = decltype(st_c)::value;
+        // (the tile minimum is recomputed here, on the cold path, rather than kept live across the
+        //  branch: the 128-deep fp32 kernel has no register to spare)
+        tighten(st_c, tile_min(acc, st_c));
         if constexpr (T16) {
             const f32x4 &lo = acc.template at<0, st>();
             const f32x4 &hi = acc.template at<1, st>();
@@ -576,6 +581,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                     constexpr int st = decltype(st_c)::value;
                     if (hm[st] != 0ull) {
                         const f32x4 &o = acc.template at<ot, st>();
+                        tighten(st_c, tmh[st]);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) record(st_c, o[r], jbase + r);
                     }
@@ -920,8 +926,8 @@ template <class OP>
 static int launch_filter_t(const FilterGeom &g, const FilterArgs &args, hipStream_t st)
 {
     auto kern = filter_kernel<OP>;
-    // 16x16 tiles: + 2 KiB per wave for the lanes' tau constants
-    constexpr int lds_bytes = F_LDS_BYTES + (OP::kTile16 ? OP::kNW * 2048 : 0);
+    // + 2 KiB per wave for the lanes' tau constants
+    constexpr int lds_bytes = F_LDS_BYTES + OP::kNW * 2048;
     // > 64 KiB of dynamic LDS needs the opt-in, once per device
     static std::atomic<bool> attr_set[64];   // (two threads racing here both set it: harmless)
     int dev = 0;
@@ -967,14 +973,22 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
         std::vector<unsigned long long> h(nwg * 4);
         NNS_HIP(hipStreamSynchronize(st));
         NNS_HIP(hipMemcpy(h.data(), a.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        std::vector<double> ghz;
+        std::vector<double> ghz, us;
+        unsigned long long first = ~0ull, last = 0;
         for (size_t w = 0; w < nwg; ++w)
-            if (h[4 * w + 3] > h[4 * w + 1])
+            if (h[4 * w + 3] > h[4 * w + 1]) {
                 ghz.push_back((double)(h[4 * w + 2] - h[4 * w]) / (double)(h[4 * w + 3] - h[4 * w + 1]) * 0.1);
+                us.push_back((double)(h[4 * w + 3] - h[4 * w + 1]) * 0.01);   // 100 MHz ticks
+                first = std::min(first, h[4 * w + 1]);
+                last = std::max(last, h[4 * w + 3]);
+            }
         std::sort(ghz.begin(), ghz.end());
+        std::sort(us.begin(), us.end());
         if (!ghz.empty())
-            fprintf(stderr, "[nns] filter in-kernel clock: median %.3f GHz (min %.3f, max %.3f) over %zu workgroups\n",
-                    ghz[ghz.size() / 2], ghz.front(), ghz.back(), ghz.size());
+            fprintf(stderr, "[nns] filter in-kernel clock: median %.3f GHz (min %.3f, max %.3f) over %zu workgroups; "
+                            "workgroup main loop %.1f us median (%.1f .. %.1f), first start to last end %.1f us\n",
+                    ghz[ghz.size() / 2], ghz.front(), ghz.back(), ghz.size(), us[us.size() / 2], us.front(), us.back(),
+                    (double)(last - first) * 0.01);
         (void)hipFree(a.stamps);
     }
     return rc;
