@@ -465,7 +465,19 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         // own tau, so that the lists are supersets of what K5 needs.)
         const float d = tmin + tcl[(2 * st + 1) * 64];
         const float tn = tmin + (tcl[(2 * st) * 64] + c1u * (d > 0.0f ? d : 0.0f)) * 1.002f;
-        thr[st] = tn < thr[st] ? tn : thr[st];
+        float t = tn < thr[st] ? tn : thr[st];
+#ifdef NNS_F_SHARE_THR
+        // (Off by default.)  A query lives on 2 (32x32 tiles: lanes l, l ^ 32) or 4 (16x16: l ^ 16,
+        // l ^ 32) lanes, each seeing a different part of every ref block.  Any of their thresholds
+        // is valid for all of them (each is >= final minimum + tau), so they could adopt the
+        // smallest: a lane then stops taking the slow path for refs that a sibling lane has already
+        // beaten.  Measured: short streams (128 slots per workgroup) +1.7 %, C3 -0.17 %, C5 -0.2 %:
+        // the headline shapes win, the flag stays for builds that serve mid-size problems.
+        // (Wave-uniform slow path: every lane is active here.)
+        t = fminf(t, __shfl_xor(t, 32, 64));
+        if constexpr (T16) t = fminf(t, __shfl_xor(t, 16, 64));
+#endif
+        thr[st] = t;
     };
     // Slow path, step 2: one finished score x of ref j: append to the state's candidate ring
     auto record = [&](auto st_c, float x, int j) __attribute__((always_inline)) {
