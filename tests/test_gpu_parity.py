@@ -815,3 +815,18 @@ def test_pool_can_be_disabled():
     env = dict(os.environ, NNS_POOL_BYTES="0")
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
+
+
+@pytest.mark.timeout(600)
+def test_short_randomised_sweep():
+    """A 20-second slice of tools/fuzz_parity.py (random shapes, data families, dtypes, paths, shards,
+    opt-in bf16 filter) with a fixed seed: every case must match the oracle bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--seconds", "20", "--seed", "11"],
+                         cwd=root, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    last = out.stdout.strip().splitlines()[-1]
+    assert last.startswith("fuzz_parity:") and " 0 failures" in last, last
+    assert int(last.split()[1]) > 200      # it did run a few hundred cases
