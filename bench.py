@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the nearest-neighbour hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): query-point-pairs/s = m * n_total / t, plus the achieved
-fraction of the fp32-MFMA roofline of the dominant kernel.
+N = 1 runs in this process.  N > 1 needs one rank per GPU: when bench.py is started WITHOUT a
+launcher (no RANK / WORLD_SIZE in the environment) it starts the N ranks itself — fresh child
+processes under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1 ...`, before this process has made any GPU call — relays rank 0's JSON line and exits
+with the launcher's code.  Started by that launcher directly it is one of the ranks.
 
-Workload (default `c3`, the configuration the metric is quoted on): 65536 queries x
-1048576 refs x 128-D fp32, synthetic uniform [0,1) clouds from the in-repo
-counter-based generator (seed 1000; queries stream then refs stream, echoing the
-reference driver main.cu:27-34, :54).  With N GPUs the refs are sharded 1048576 per
-GPU (C4 at N = 8: 65536 x 8388608 x 128) — weak scaling; queries are replicated; the
-only exchange is ONE min all-reduce of m packed (distance, index) keys (RCCL).
+Metric (BASELINE.json): query-point-pairs/s = m * n_total / t, plus the achieved fraction of
+the roofline of the dominant kernel.
+
+Workload (default `c3`, the configuration the metric is quoted on): 65536 queries x 1048576
+refs x 128-D fp32, synthetic uniform [0,1) clouds from the in-repo counter-based generator
+(seed 1000; queries stream then refs stream, echoing the reference driver main.cu:27-34, :54).
+With N GPUs the refs are sharded 1048576 per GPU (C4 at N = 8: 65536 x 8388608 x 128) — weak
+scaling; queries are replicated; the only exchange is ONE min all-reduce of m packed
+(distance, index) keys: ncclAllReduce(uint64, min) issued by the library (nns_comm_allreduce_min,
+the same call site as nns_search_f32_multi's), torch.distributed's all_reduce if that
+communicator cannot be built.
 
 A step = one pass of the hot path over the batch, inputs already resident in HBM:
   K2 ref pre-pass (centre + MFMA tile image + norms)  -> nns_index_refresh
@@ -20,14 +27,19 @@ A step = one pass of the hot path over the batch, inputs already resident in HBM
   re-rank of ambiguous queries                         -> nns_index_search
   [N > 1] all-reduce(min) of the keys over RCCL
   unpack keys -> int32 indices                         -> nns_keys_unpack
-(the reference times alloc + H2D + D2H too, main.cu:73-75; the PCIe-inclusive figure
-of the whole-call drop-in is reported in DESIGN.md, never here).
+(the reference times alloc + H2D + D2H too, main.cu:73-75; the PCIe-inclusive figure of the
+whole-call drop-in is reported in DESIGN.md, never here).
+
+At N = 1 the default run also measures, after the headline and outside its timed region, the
+other single-GPU configurations of BASELINE.json (C1, C2, C5) with the same fields: `also`.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -44,12 +56,12 @@ import __graft_entry__ as graft  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA, spec (155 measured)
 PEAK_F32_VALU_TFLOPS = 157.3   # fp32 vector peak (FMA-counted)
 PEAK_HBM_GBS = 8000.0
-
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # bf16 dense MFMA, spec
 
 WORKLOADS = {
     # name: (m, n_per_gpu, k, dtype)
     "c3": (65536, 1048576, 128, "f32"),     # the configuration the metric is quoted on
+    "c1": (1024, 4096, 3, "f32"),           # BASELINE config 1: the reference's own CPU-runnable case
     "c2": (4096, 65536, 3, "f32"),          # per-pair exact kernel, no MFMA
     "c5": (131072, 2097152, 256, "bf16"),   # bf16 points, fp32 accumulate
     "c3s": (8192, 131072, 128, "f32"),      # quick look, not a reported config
@@ -59,11 +71,29 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(orc, q_h, r_dev, idx_gpu, target_s=12.0):
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """Started without a launcher and asked for N > 1 GPUs: become the launcher.  Nothing in this
+    process has touched the GPU yet (importing torch does not), so the ranks are clean children."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")        # what torchrun would set, without its warning
+    proc = subprocess.run(cmd, env=env)           # stdout / stderr inherited: rank 0's JSON line is ours
+    raise SystemExit(proc.returncode)
+
+
+def cpu_baseline(orc, q_h, r_h, idx_gpu, target_s=12.0, full=False):
     """V0 on the host, single thread, on a bounded sample: the first `s` queries of the
-    workload against ALL of this GPU's refs.  Uses the reference's own V0 binary when it
-    was built (oracle/_ref), else our restatement.  Also cross-checks the GPU indices."""
-    r_h = r_dev.cpu().numpy()
+    workload against ALL of this GPU's refs (`full`: every query).  Uses the reference's own V0
+    binary when it was built (oracle/_ref), else our restatement.  Also cross-checks the GPU indices."""
     n = r_h.shape[0]
     use_ref = orc.have_reference()
 
@@ -75,13 +105,16 @@ def cpu_baseline(orc, q_h, r_dev, idx_gpu, target_s=12.0):
             idx, _ = orc.v0_search(q_h[:s], r_h)
         return time.perf_counter() - t0, idx
 
-    t1, _ = run(1)
-    s = int(max(1, min(q_h.shape[0], target_s / max(t1, 1e-6))))
+    if full:
+        s = q_h.shape[0]
+    else:
+        t1, _ = run(1)
+        s = int(max(1, min(q_h.shape[0], target_s / max(t1, 1e-6))))
     t, idx = run(s)
     ok = bool(np.array_equal(idx, idx_gpu[:s]))
     out = {"value": s * n / t, "unit": "pairs/s", "cores": 1,
            "kind": "reference" if use_ref else "port",
-           "sample": f"first {s} queries x all {n} refs of the workload, {t:.1f} s, V0 single thread"
+           "sample": f"{'all' if full else 'first'} {s} queries x all {n} refs of the workload, {t:.1f} s, V0 single thread"
                      f"{' (reference core.cu:11-54 built -O2 -ffp-contract=off)' if use_ref else ''}",
            "matches_gpu_indices": ok}
     # all host cores (OpenMP over queries, our restatement) for scale
@@ -97,71 +130,57 @@ def cpu_baseline(orc, q_h, r_dev, idx_gpu, target_s=12.0):
         t2 = time.perf_counter() - t0
         out["all_cores"] = {"value": s2 * n / t2, "cores": cores, "kind": "port",
                             "matches_gpu_indices": bool(np.array_equal(idx2, idx_gpu[:s2]))}
-    # low-dimensional workloads: the reference's other working algorithm family (V10's CPU k-d
-    # tree, core.cu:1060-1163, which itself bails out above 16 dimensions) as a second comparator;
-    # oracle/kdtree.c is exact with V0's semantics (equivalent pairs/s = m * n / t, build included)
+    # low-dimensional workloads: the reference's other working algorithm families (V10's CPU k-d
+    # tree, core.cu:1060-1163, which itself bails out above 16 dimensions; V12's CPU octree,
+    # core.cu:1454-1659, 3-D only) as further comparators; oracle/kdtree.c and oracle/octree.c are
+    # exact with V0's semantics (equivalent pairs/s = m * n / t, build included)
     if q_h.shape[1] <= 16 and np.isfinite(r_h).all() and np.isfinite(q_h).all():
-        t0 = time.perf_counter()
-        idx3, _ = orc.kdtree_search(q_h, r_h, threads=cores)
-        t3 = time.perf_counter() - t0
-        out["kdtree"] = {"value": q_h.shape[0] * n / t3, "unit": "pairs/s (equivalent: m*n / wall time incl. build)",
+        trees = [("kdtree", orc.kdtree_search)]
+        if q_h.shape[1] == 3 and hasattr(orc, "octree_search"):
+            trees.append(("octree", orc.octree_search))
+        for name, fn in trees:
+            t0 = time.perf_counter()
+            idx3, _ = fn(q_h, r_h, threads=cores)
+            t3 = time.perf_counter() - t0
+            out[name] = {"value": q_h.shape[0] * n / t3, "unit": "pairs/s (equivalent: m*n / wall time incl. build)",
                          "cores": cores, "kind": "port", "queries": int(q_h.shape[0]), "seconds": t3,
                          "matches_gpu_indices": bool(np.array_equal(idx3, idx_gpu[:q_h.shape[0]]))}
     return out
 
 
 def load_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed PMC run
-    (profiles/traffic.json, produced by tools/pmc_traffic.py from rocprofv3 --pmc
-    passes, FETCH_SIZE x2-corrected per MI355X_MICROARCH.md); None if absent."""
+    """HBM bytes per launch of the dominant kernel from the committed PMC run (profiles/traffic.json,
+    produced by tools/pmc_traffic.py from separate rocprofv3 --pmc passes over this same command,
+    FETCH_SIZE x2-corrected per MI355X_MICROARCH.md).  NOT measured inside this run: counters cannot
+    be read from within the process; `traffic_source` in the line says so.  (None, None) if absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(kernel_key)
+            d = json.load(f)
+        v = d.get(kernel_key)
+        return (v, "profiles/traffic.json[%s]: rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE per launch, collected "
+                   "in separate passes over this command, not in this run" % kernel_key) if v is not None else (None, None)
     except Exception:
-        return None
+        return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (NOT a measurement):
-    # every rank on cuda:0, keys exchanged through gloo on the host instead of RCCL
-    ap.add_argument("--rehearse-one-gpu", action="store_true")
-    ap.add_argument("--verify", action="store_true", help="rank 0 checks the merged indices against the unsharded search")
-    args = ap.parse_args()
+class Ctx:
+    """What one rank needs to run workloads."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    if args.rehearse_one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run: one rank per GPU
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        if args.rehearse_one_gpu:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    def __init__(self, pkg, dev, rank, world, dist=None, comm=None, rehearse=False):
+        self.pkg, self.dev, self.rank, self.world = pkg, dev, rank, world
+        self.dist, self.comm, self.rehearse = dist, comm, rehearse
 
-    pkg = graft.load_package()
-    m, n_local, k, dtype = WORKLOADS[args.workload]
-    path = "auto"
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+
+def run_workload(ctx, name, steps, warmup, seed=1000):
+    """W untimed + K timed steps of workload `name`; returns (report dict, idx, q, r, keys_local_fn)."""
+    pkg, dev, rank, world, dist = ctx.pkg, ctx.dev, ctx.rank, ctx.world, ctx.dist
+    m, n_local, k, dtype = WORKLOADS[name]
     n_total = n_local * world
-    seed = 1000
 
     # synthetic clouds, generated on the device (same bits as the CPU generator)
     q = torch.empty((m, k), dtype=torch.float32, device=dev)
@@ -174,95 +193,230 @@ def main():
         r = r.to(torch.bfloat16)
         torch.cuda.empty_cache()
     keys = torch.empty(m, dtype=torch.int64, device=dev)
-    mixed = args.workload == "c3x"
-    ix = pkg.Index(r, index_base=beg, path=path, profile=True, filter_bf16=mixed)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    mixed = name == "c3x"
+    ix = pkg.Index(r, index_base=beg, path="auto", profile=True, filter_bf16=mixed)
 
     def step():
         ix.refresh()                          # K2 on refs
         ix.search_keys(q, keys)               # K2 queries, K3 filter, K5, re-rank
         if dist is not None:
-            pkg.allreduce_min_keys(keys)      # MINLOC-style exchange: one min all-reduce
+            pkg.allreduce_min_keys(keys, comm=ctx.comm)   # MINLOC-style exchange: one min all-reduce
         return pkg.keys_unpack(keys)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     stage = {"filter_ms": 0.0, "exact_ms": 0.0, "prep_refs_ms": 0.0, "prep_queries_ms": 0.0,
              "finalize_ms": 0.0, "rerank_ms": 0.0}
-    amb = 0
     ix.stats()                                # drop the warm-up steps' event sets
-    barrier()
+    ctx.barrier()
     t0 = time.perf_counter()
     done = 0
-    for i in range(args.steps):
+    idx = None
+    for i in range(steps):
         idx = step()
         # HIP events of every step's kernels are recorded on the launch stream inside the
         # library; read (= one device sync) every 32 steps at most: its ring of event sets
-        if (i + 1) % 32 == 0 and i + 1 < args.steps:
+        if (i + 1) % 32 == 0 and i + 1 < steps:
             st = ix.stats()
             for f in stage:
                 stage[f] += st[f] * 32
             done += 32
-    barrier()
+    ctx.barrier()
     elapsed = time.perf_counter() - t0
     st = ix.stats()                           # averages over the steps not read yet
     for f in stage:
-        stage[f] += st[f] * (args.steps - done)
+        stage[f] += st[f] * (steps - done)
     amb = st["ambiguous"]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_one_gpu else dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if ctx.rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     for f in stage:
-        stage[f] /= max(1, args.steps)
+        stage[f] /= max(1, steps)
 
-    ms_per_step = elapsed / args.steps * 1e3
-    value = m * float(n_total) / (elapsed / args.steps)
+    ms_per_step = elapsed / steps * 1e3
+    value = m * float(n_total) / (elapsed / steps)
+    mfma_path = st["path"] == 2
+    bf_ops = dtype == "bf16" or mixed
+    if mfma_path:
+        kern_ms = stage["filter_ms"]
+        flops = 2.0 * m * n_local * k       # algorithmic: 2*k flop per pair
+        achieved = flops / (kern_ms * 1e-3) / 1e12
+        peak = PEAK_BF16_MFMA_TFLOPS if bf_ops else PEAK_F32_MFMA_TFLOPS
+        traffic, tsrc = load_traffic(f"filter_{'bf16' if bf_ops else 'f32'}_{name}")
+        roof = {"bound": "mfma", "kernel": f"filter_kernel<{'OpBF16' if bf_ops else 'OpF32'}> (kt={st['k_tile']})",
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "kernel_ms": kern_ms, "flop_per_pair": 2 * k, "traffic": traffic}
+    else:
+        kern_ms = stage["exact_ms"]
+        flops = 3.0 * k * m * n_local       # sub, mul, add per dim
+        achieved = flops / (kern_ms * 1e-3) / 1e12
+        traffic, tsrc = load_traffic(f"exact_{name}")
+        roof = {"bound": "valu", "kernel": "exact_lane_query_kernel", "achieved": achieved,
+                "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_VALU_TFLOPS,
+                "kernel_ms": kern_ms, "flop_per_pair": 3 * k, "traffic": traffic,
+                "hbm_GBs_algorithmic": ((m + n_local) * k * 4 + 4 * m) / (kern_ms * 1e-3) / 1e9}
+    if tsrc:
+        roof["traffic_source"] = tsrc
+    out = {
+        "metric": "query-point-pairs/s", "value": value, "unit": "pairs/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16 points, f32 accumulate" if dtype == "bf16"
+        else ("f32 points, bf16 filter operands, f32 accumulate, exact f32 re-rank (opt-in extra)" if mixed else "f32"),
+        "data": "synthetic",
+        "config": {"workload": f"{name}: {m} queries x {n_total} refs x {k}-D {dtype}"
+                               f" ({n_local} refs per GPU x {world} GPU)",
+                   "m": m, "n": n_total, "k": k, "refs_per_gpu": n_local,
+                   "path": "mfma-filter+exact-rerank" if mfma_path else "exact-valu",
+                   "ambiguous_queries": amb, "stage_ms": {f: round(v, 4) for f, v in stage.items()}},
+        "roofline": roof,
+    }
+    return out, idx, q, r, ix, keys
+
+
+def selftest_launch(args):
+    """CPU-only check of the N > 1 launch plumbing (tests/test_bench_launch.py): the ranks
+    rendezvous over gloo, exchange synthetic packed keys with the product's exchange function and
+    rank 0 prints one JSON line.  No GPU, no search: NOT a measurement."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    pkg = graft.load_package()
+    m, n_total = 1000, 1000 * world
+    beg, cnt = pkg.shard_range(n_total, world, rank)
+    # rank r "finds" distance (i * 7 + r * 3) % 11 at local index i % cnt for query i
+    i = torch.arange(m, dtype=torch.int64)
+    d = ((i * 7 + rank * 3) % 11).to(torch.float32)
+    keys = (d.view(torch.int32).to(torch.int64) << 32) | (beg + (i % cnt))
+    pkg.allreduce_min_keys(keys)
+    # every rank can compute the expected merge
+    want = None
+    for rr in range(world):
+        b, c = pkg.shard_range(n_total, world, rr)
+        kk = ((((i * 7 + rr * 3) % 11).to(torch.float32)).view(torch.int32).to(torch.int64) << 32) | (b + (i % c))
+        want = kk if want is None else torch.minimum(want, kk)
+    ok = torch.tensor([1 if torch.equal(keys, want) else 0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"selftest": "launch", "n_gpus": world, "ok": bool(ok.item()),
+                          "note": "gloo rendezvous + key exchange only: not a measurement"}), flush=True)
+    dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the C1 / C2 / C5 block of the default N = 1 run")
+    # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (NOT a measurement):
+    # every rank on cuda:0, keys exchanged through gloo on the host instead of RCCL
+    ap.add_argument("--rehearse-one-gpu", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="rank 0 checks the merged indices against the unsharded search")
+    ap.add_argument("--exchange", default="auto", choices=("auto", "library", "torch"),
+                    help="N > 1: who issues the RCCL min all-reduce (auto: the library, torch.distributed if that fails)")
+    ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1:
+        self_launch(args.gpus)                # never returns
+    if args.selftest_launch:
+        return selftest_launch(args)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    if args.rehearse_one_gpu:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible); "
+                         "one rank per GPU (use --rehearse-one-gpu to rehearse the code path on fewer)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if launched:                              # one rank per GPU
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if args.rehearse_one_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = graft.load_package()
+
+    # ---- the exchange of the N > 1 form ------------------------------------------------------------
+    comm, exch = None, None
+    if dist is not None:
+        exch = {"impl": "torch.distributed all_reduce(int64, MIN) "
+                        + ("over gloo (rehearsal)" if args.rehearse_one_gpu else "over RCCL")}
+        if not args.rehearse_one_gpu and args.exchange != "torch":
+            # rank 0 draws RCCL's unique id, torch.distributed carries its 128 bytes, every rank joins
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid[0] = pkg.comm_unique_id()
+                except pkg.NNSError as e:
+                    exch["library_comm_error"] = str(e)
+            dist.broadcast_object_list(uid, src=0, device=dev)
+            if uid[0] is not None:
+                try:
+                    comm = pkg.Comm(uid[0], world, rank, local_rank)
+                except pkg.NNSError as e:
+                    comm = None
+                    exch["library_comm_error"] = str(e)
+            ok = torch.tensor([1 if comm is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
+            if comm is not None:
+                exch = {"impl": "nns_comm_allreduce_min: ncclAllReduce(ncclUint64, ncclMin) issued by libnns_mi355x "
+                                "(the call site nns_search_f32_multi uses)", "rccl_ranks": comm.size()}
+            elif args.exchange == "library":
+                raise SystemExit(f"--exchange library: {exch.get('library_comm_error', 'communicator not built')}")
+
+    ctx = Ctx(pkg, dev, rank, world, dist, comm, args.rehearse_one_gpu)
+    out, idx, q, r, ix, keys = run_workload(ctx, args.workload, args.steps, args.warmup)
+    m, n_local, k, dtype = WORKLOADS[args.workload]
+    n_total = n_local * world
+
+    if dist is not None:
+        # outside the timed region: both exchange routes must give the same bits
+        loc = ix.search_keys(q).clone()
+        a = loc.clone()
+        pkg.allreduce_min_keys(a, comm=comm)
+        b = loc.clone()
+        pkg.allreduce_min_keys(b)             # torch.distributed
+        torch.cuda.synchronize()
+        same = torch.tensor([1 if torch.equal(a, b) else 0], device="cpu" if args.rehearse_one_gpu else dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        exch["matches_torch_all_reduce"] = bool(int(same.item()))
+        # a rank's own keys must survive the merge somewhere (sanity: shards really differ)
+        won = torch.tensor([int((a == loc).sum().item())], device="cpu" if args.rehearse_one_gpu else dev)
+        dist.all_reduce(won, op=dist.ReduceOp.SUM)
+        exch["queries_won_sum_over_ranks"] = int(won.item())   # >= m (== m without cross-shard exact ties)
 
     if rank == 0:
-        mfma_path = st["path"] == 2
-        if mfma_path:
-            kern_ms = stage["filter_ms"]
-            flops = 2.0 * m * n_local * k       # algorithmic: 2*k flop per pair
-            achieved = flops / (kern_ms * 1e-3) / 1e12
-            peak = PEAK_BF16_MFMA_TFLOPS if (dtype == "bf16" or mixed) else PEAK_F32_MFMA_TFLOPS
-            roof = {"bound": "mfma", "kernel": f"filter_kernel<{'OpBF16' if (dtype == 'bf16' or mixed) else 'OpF32'}>",
-                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "kernel_ms": kern_ms, "flop_per_pair": 2 * k,
-                    "traffic": load_traffic(f"filter_f32_{args.workload}")}
-        else:
-            kern_ms = stage["exact_ms"]
-            flops = 3.0 * k * m * n_local       # sub, mul, add per dim
-            achieved = flops / (kern_ms * 1e-3) / 1e12
-            roof = {"bound": "valu", "kernel": "exact_lane_query_kernel", "achieved": achieved,
-                    "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_VALU_TFLOPS,
-                    "kernel_ms": kern_ms, "flop_per_pair": 3 * k,
-                    "traffic": load_traffic(f"exact_{args.workload}")}
-        out = {
-            "metric": "query-point-pairs/s", "value": value, "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16 points, f32 accumulate" if dtype == "bf16"
-            else ("f32 points, bf16 filter operands, f32 accumulate, exact f32 re-rank (opt-in extra)" if mixed else "f32"),
-            "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {m} queries x {n_total} refs x {k}-D {dtype}"
-                                   f" ({n_local} refs per GPU x {world} GPU)",
-                       "m": m, "n": n_total, "k": k, "refs_per_gpu": n_local,
-                       "path": "mfma-filter+exact-rerank" if mfma_path else "exact-valu",
-                       "ambiguous_queries": amb, "stage_ms": {f: round(v, 4) for f, v in stage.items()}},
-            "roofline": roof,
-        }
+        if exch is not None:
+            out["exchange"] = exch
         if args.rehearse_one_gpu:
             out["rehearsal"] = "all ranks on one GPU, gloo exchange: NOT a measurement"
         if args.verify:
             # the merged answer must equal one unsharded search over all n_total refs
             r_all = torch.empty((n_total, k), dtype=torch.float32, device=dev)
-            pkg.fill_uniform(r_all, seed, m * k)
+            pkg.fill_uniform(r_all, 1000, m * k)
             if dtype == "bf16":
                 r_all = r_all.to(torch.bfloat16)
             ix_all = pkg.Index(r_all)
@@ -271,12 +425,39 @@ def main():
             out["verified_vs_unsharded"] = bool(torch.equal(want, idx))
             ix_all.close()
             del r_all
+        orc = None
         if world == 1 and not args.no_cpu_baseline:
             orc = graft.load_oracle()          # cpu_baseline leg only
-            out["cpu_baseline"] = cpu_baseline(orc, q[:4096].float().cpu().numpy(), r.float(), idx.cpu().numpy())
-        print(json.dumps(out), flush=True)
+            out["cpu_baseline"] = cpu_baseline(orc, q[:4096].float().cpu().numpy(), r.float().cpu().numpy(),
+                                               idx.cpu().numpy())
     ix.close()
+    del q, r, keys, ix
+    torch.cuda.empty_cache()
+
+    # ---- the other single-GPU configurations of BASELINE.json, same fields, same run ------------------
+    if rank == 0 and world == 1 and args.workload == "c3" and not args.no_also:
+        also = {}
+        for name, (st_, wu_) in (("c2", (200, 20)), ("c5", (5, 1)), ("c1", (200, 20))):
+            o, idx2, q2, r2, ix2, keys2 = run_workload(ctx, name, st_, wu_)
+            ent = {"value": o["value"], "unit": "pairs/s", "ms_per_step": o["ms_per_step"], "steps": st_, "warmup": wu_,
+                   "dtype": o["dtype"], "config": o["config"], "roofline": o["roofline"]}
+            if orc is not None:
+                full = name == "c1"            # C1 is the reference's CPU-runnable case: V0 over the whole problem
+                ent["cpu_baseline"] = cpu_baseline(orc, q2[:4096].float().cpu().numpy(), r2.float().cpu().numpy(),
+                                                   idx2.cpu().numpy(), target_s=4.0, full=full)
+            also[name] = ent
+            ix2.close()
+            del q2, r2, keys2, ix2
+            torch.cuda.empty_cache()
+            pkg.trim()
+        out["also"] = also
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

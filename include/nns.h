@@ -82,7 +82,7 @@ enum {
     NNS_REFS_SOA = 64    /* the reference points are given dimension-major, r[t * n + j] (a dense [k][n]
                           * array: the layout v4::mat_inv_kernel produces, core.cu:293-306, :327) instead
                           * of r[j * k + t]; queries stay [m][k].  The library transposes once on the
-                          * device into a copy it owns.  Not accepted by nns_search_f32_multi. */
+                          * device into a copy it owns. */
 };
 
 /*
@@ -115,6 +115,8 @@ typedef struct nns_stats {
     float rerank_ms;       /* exact scan of ambiguous queries */
     float exact_ms;        /* exact path kernels (K1) */
     float total_ms;        /* all device work of a search */
+    int multi_candidate;   /* queries whose filter margin was below tau: K5 chose among > 1 candidates with
+                            * V0's arithmetic (nns_index_near_ties lists them) */
 } nns_stats;
 
 /* ---- whole-call drop-ins (host pointers; alloc + H2D + kernels + D2H) ------ */
@@ -139,10 +141,16 @@ int nns_search_f32_ex(int k, int m, int n, const float *s_points,
  * keys combined with ONE RCCL min all-reduce (uint64, ncclMin) over xGMI; falls back
  * to one GPU for small problems exactly as the reference does (core.cu:775-777:
  * n <= min(2^18, 1024 m)).  Result = V0's, for every m (the reference's own merge
- * is wrong for m > 1). */
+ * is wrong for m > 1).  The RCCL communicators of a device set are created
+ * on the first call and cached for the life of the process (nns_shutdown() destroys
+ * them); concurrent multi calls of one process are serialised around the collective.
+ * NNS_REFS_SOA is accepted (a shard is then a column range of the [k][n] array). */
 int nns_search_f32_multi(int k, int m, int n, const float *s_points,
                          const float *r_points, int *idx_out, float *dist_out,
                          int num_devices, unsigned flags);
+int nns_search_bf16_multi(int k, int m, int n, const uint16_t *s_points,
+                          const uint16_t *r_points, int *idx_out, float *dist_out,
+                          int num_devices, unsigned flags);
 
 /* ---- split API (device-resident buffers, caller's stream) ------------------ */
 
@@ -181,6 +189,14 @@ int nns_search_bf16_ex(int k, int m, int n, const uint16_t *s_points,
 
 int nns_index_stats(nns_index *ix, nns_stats *out);
 
+/* The queries of the LAST nns_index_search on the MFMA path whose answer was NOT settled by the
+ * filter alone: more than one reference lay within the proof margin tau of the filter's minimum and
+ * K5 decided among them with V0's exact arithmetic (queries sent to the exact scan are counted by
+ * nns_stats.ambiguous instead).  *count_out = how many; up to `cap` query numbers are copied into
+ * ids_out (host memory, any order).  Synchronises the device.  These are the queries a parity check
+ * at sizes beyond the oracle's reach should verify in full (SURVEY 8d's "filter margin" gate). */
+int nns_index_near_ties(nns_index *ix, int *ids_out, int cap, int *count_out);
+
 /* inout[i] = min(inout[i], other[i]) : the cross-shard merge operator. */
 int nns_keys_min(nns_key *inout_dev, const nns_key *other_dev, int m, void *stream);
 
@@ -203,6 +219,32 @@ int nns_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset,
  * fp64).  These are the error models behind the filter's proof margin tau. */
 int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const float *c0,
                       float *out);
+/* Diagnostic (host only): the constants of the proof margin tau(a) = c0 + c1 * max(a + x2, 0) the
+ * filter and K5 use for a query of squared norm qnorm2 against refs of maximum squared norm ymax2 at
+ * tile depth kt; mode 0 fp32 operands, 1 bf16 points, 2 fp32 points rounded to bf16 operands.
+ * out3 = {c0, c1, x2}.  Lets the tests hold the measured MFMA error against the model. */
+int nns_tau_consts(int kt, float qnorm2, float ymax2, int mode, float *out3);
+
+/* ---- the exchange of the one-process-per-GPU form ----------------------------
+ * What V8/V9's gather + host re-rank (core.cu:821-852, 1025-1056) becomes when every GPU
+ * has its own process (bench.py --gpus N under torch.distributed.run): each rank searches
+ * its contiguous ref shard (nns_index_create with index_base = shard offset, core.cu:781-791,
+ * :827-829) and the ranks combine their packed keys with ONE
+ * ncclAllReduce(ncclUint64, ncclMin) over xGMI.  Same call site as nns_search_*_multi.
+ *   rank 0:     nns_comm_unique_id(id, sizeof id)      (RCCL's ncclUniqueId, 128 bytes)
+ *   caller:     carries the id bytes to every rank (MPI, a file, torch.distributed, ...)
+ *   every rank: nns_comm_create(&c, id, sizeof id, nranks, rank, device)   (collective)
+ *               nns_comm_allreduce_min(c, keys_dev, m, stream)            (async, in place)
+ *               nns_comm_destroy(c)
+ * librccl is dlopen()ed on first use; NNS_ERR_UNSUPPORTED if it cannot be loaded. */
+#define NNS_COMM_ID_BYTES 128
+typedef struct nns_comm nns_comm;
+int nns_comm_unique_id(void *id_out, size_t id_bytes);
+int nns_comm_create(nns_comm **out, const void *id, size_t id_bytes, int nranks,
+                    int rank, int device);
+int nns_comm_size(nns_comm *c);   /* ranks RCCL reports for the communicator (0 on error) */
+int nns_comm_allreduce_min(nns_comm *c, nns_key *keys_dev, int m, void *stream);
+int nns_comm_destroy(nns_comm *c);
 
 /* ---- misc ------------------------------------------------------------------ */
 int nns_device_count(void);
@@ -221,6 +263,10 @@ int nns_warmup(int device);
  * parked blocks back and returns the number of bytes released.  NNS_POOL_BYTES in the
  * environment caps what the pool may hold (default 16 GiB; 0 disables pooling). */
 size_t nns_trim(void);
+/* Destroys the cached RCCL communicators of nns_search_*_multi and trims the pool: call once
+ * when the process is done with the library (optional; indexes and nns_comm handles are the
+ * caller's to destroy). */
+int nns_shutdown(void);
 
 #ifdef __cplusplus
 }

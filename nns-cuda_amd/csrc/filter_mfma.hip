@@ -117,8 +117,15 @@ struct AccSet16 {
     }
 };
 
-// Timing diagnostics only (results are wrong): build with -DNNS_FILTER_ABLATE=<bits>
-//   1 no ring sync (wait + barrier), 2 no epilogue, 16 no DMA issue.  0 in the product.
+// Timing diagnostics only (results are wrong): build with -DNNS_DIAG -DNNS_FILTER_ABLATE=<bits>
+//   1 no ring sync (wait + barrier), 2 no epilogue, 16 no DMA issue.  The product build (no NNS_DIAG)
+// has none of the diagnostic switches: no ablation, no NNS_FILTER_CLOCK / NNS_DIAG_FILTER_ONLY
+// environment variables (tests/test_abi_cpu.py greps the shipped library for them).
+#if !defined(NNS_DIAG)
+#undef NNS_FILTER_ABLATE
+#undef NNS_F_NOLATCHFENCE
+#undef NNS_F_NOLAG
+#endif
 #ifndef NNS_FILTER_ABLATE
 #define NNS_FILTER_ABLATE 0
 #endif
@@ -306,7 +313,9 @@ struct FilterArgs {
     int *counts;            // [splits][m_pad/32][64 lanes]
     int total_slots, slots_per_split, m_pad, kt;
     int bf16;               // tau mode: 0 fp32 operands, 1 bf16 points, 2 fp32 points rounded to bf16 operands
+#ifdef NNS_DIAG
     unsigned long long *stamps;   // diagnostic (NNS_FILTER_CLOCK): per-workgroup s_memtime / s_memrealtime
+#endif
 };
 
 template <class OP>
@@ -369,11 +378,13 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     }
     const float c1u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tc[0].c1)));
 
+#ifdef NNS_DIAG
     unsigned long long st_t0 = 0, st_r0 = 0;
     if (a.stamps) {   // diagnostic launches only: in-kernel clock = d(memtime) / d(memrealtime) * 100 MHz
         st_t0 = __builtin_amdgcn_s_memtime();
         st_r0 = __builtin_amdgcn_s_memrealtime();
     }
+#endif
     const int slot0 = blockIdx.y * a.slots_per_split;
     int ns = a.total_slots - slot0;
     if (ns > a.slots_per_split) ns = a.slots_per_split;
@@ -801,6 +812,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     }
 #pragma unroll
     for (int st = 0; st < NS; ++st) a.counts[(lblk0 + st) * 64 + lane] = cnt[st];
+#ifdef NNS_DIAG
     if (a.stamps && threadIdx.x == 0) {
         unsigned long long *o = a.stamps + 4 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
         o[0] = st_t0;
@@ -808,6 +820,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         o[2] = __builtin_amdgcn_s_memtime();
         o[3] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
 }
 
 // ---- self-test: one 32x32 tile through the same MFMA k-order as the filter --------
@@ -970,10 +983,12 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
     a.m_pad = g.m_pad;
     a.kt = g.kt;
     a.bf16 = g.mixed ? 2 : g.bf16;
+#ifdef NNS_DIAG
     a.stamps = nullptr;
     const char *clk = getenv("NNS_FILTER_CLOCK");
     const size_t nwg = (size_t)g.qgroups * g.splits;
     if (clk && atoi(clk)) NNS_HIP(hipMalloc(&a.stamps, nwg * 4 * sizeof(unsigned long long)));
+#endif
     const int rc = g.bf16 ? (g.kt == 128   ? launch_filter_t<OpBF16K128>(g, a, st)
                              : g.kt == 512 ? launch_filter_t<OpBF16K512>(g, a, st)
                                            : launch_filter_t<OpBF16Active>(g, a, st))
@@ -981,6 +996,7 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
                              : g.kt == 64  ? launch_filter_t<OpF32K64>(g, a, st)
                              : g.kt == 256 ? launch_filter_t<OpF32K256>(g, a, st)
                                            : launch_filter_t<OpF32>(g, a, st));
+#ifdef NNS_DIAG
     if (a.stamps) {   // diagnostic: synchronous read-out, median clock over workgroups
         std::vector<unsigned long long> h(nwg * 4);
         NNS_HIP(hipStreamSynchronize(st));
@@ -1003,6 +1019,7 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
                     (double)(last - first) * 0.01);
         (void)hipFree(a.stamps);
     }
+#endif
     return rc;
 }
 

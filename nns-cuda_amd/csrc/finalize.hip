@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(
     int kt, int bf16, int lpq, int m_pad, int splits, int k, int m, int n, const T *__restrict__ q,
     const T *__restrict__ r, const CandEntry *__restrict__ lists, const int *__restrict__ counts,
     const float *__restrict__ qnorm, DevScalars *__restrict__ scal, int64_t index_base,
-    nns_key *__restrict__ keys, int *__restrict__ amb_list)
+    nns_key *__restrict__ keys, int *__restrict__ amb_list, int *__restrict__ multi_list)
 {
     const int ush = lpq == 4 ? 4 : 5, qmask = (1 << ush) - 1;   // queries per list unit: 16 or 32
     const int lane = threadIdx.x & 63;
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(
     if (over || !(a < __builtin_inff())) fallback = true;
 
     nns_key best = NNS_KEY_NONE;
+    int ncand = 0;   // candidates within tau of the filter's minimum: the refs V0's arithmetic decides among
     if (!fallback && live) {
         const TauConsts tc = tau_consts(kt, qnorm[i], __uint_as_float(scal->ymax2_bits), bf16);
         const float thr = a + tau_of(tc, a);
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(
                     const float sum = v0_distance(qi, r + (size_t)ce.j * k, k, vec);
                     const nns_key key = make_key(sum, index_base + ce.j);
                     best = key < best ? key : best;
+                    ++ncand;
                 }
             }
         }
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(
         const unsigned hi = __shfl_xor((unsigned)(best >> 32), off, 64);
         const nns_key o = ((nns_key)hi << 32) | lo;
         best = o < best ? o : best;
+        ncand += __shfl_xor(ncand, off, 64);
     }
     // every candidate NaN/INF cannot happen with bounded inputs; be safe anyway
     if (best == NNS_KEY_NONE) fallback = true;
@@ -145,6 +148,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(
         if (fallback) {
             const int pos = atomicAdd(&scal->amb_count, 1);
             amb_list[pos] = i;
+        } else if (ncand > 1) {    // decided by the exact re-rank of several candidates (rare)
+            const int pos = atomicAdd(&scal->multi_count, 1);
+            multi_list[pos] = i;
         }
     }
 }
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
     int kt, int bf16, int lpq, int m_pad, int splits, int k, int m, int n, const T *__restrict__ q,
     const T *__restrict__ r, const CandEntry *__restrict__ lists, const int *__restrict__ counts,
     const float *__restrict__ qnorm, DevScalars *__restrict__ scal, int64_t index_base,
-    nns_key *__restrict__ keys, int *__restrict__ amb_list)
+    nns_key *__restrict__ keys, int *__restrict__ amb_list, int *__restrict__ multi_list)
 {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);   // wave-uniform query
@@ -186,6 +192,7 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
     if (over || !(a < __builtin_inff())) fallback = true;
 
     nns_key best = NNS_KEY_NONE;
+    int ncand = 0;
     if (!fallback) {
         const TauConsts tc = tau_consts(kt, qnorm[i], __uint_as_float(scal->ymax2_bits), bf16);
         const float thr = a + tau_of(tc, a);
@@ -204,6 +211,7 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
                     const float sum = v0_distance(qi, r + (size_t)ce.j * k, k, vec);
                     const nns_key key = make_key(sum, index_base + ce.j);
                     best = key < best ? key : best;
+                    ++ncand;
                 }
             }
         }
@@ -213,6 +221,7 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
             const unsigned hi = __shfl_xor((unsigned)(best >> 32), off, 64);
             const nns_key o = ((nns_key)hi << 32) | lo;
             best = o < best ? o : best;
+            ncand += __shfl_xor(ncand, off, 64);
         }
         if (best == NNS_KEY_NONE) fallback = true;
     }
@@ -221,13 +230,16 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
         if (fallback) {
             const int pos = atomicAdd(&scal->amb_count, 1);
             amb_list[pos] = i;
+        } else if (ncand > 1) {
+            const int pos = atomicAdd(&scal->multi_count, 1);
+            multi_list[pos] = i;
         }
     }
 }
 
 int launch_finalize(const FilterGeom &g, int k, int m, int n, const void *q, const void *r,
                     const CandEntry *lists, const int *counts, const float *qnorm, DevScalars *scal,
-                    int64_t index_base, nns_key *keys, int *amb_list, hipStream_t st)
+                    int64_t index_base, nns_key *keys, int *amb_list, int *multi_list, hipStream_t st)
 {
     const int mode = g.mixed ? 2 : g.bf16;        // tau mode (nns_internal.h)
     const bool data_bf16 = g.bf16 && !g.mixed;    // element type of q / r
@@ -235,22 +247,22 @@ int launch_finalize(const FilterGeom &g, int k, int m, int n, const void *q, con
         if (data_bf16)
             hipLaunchKernelGGL(finalize_wave_kernel<uint16_t>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, mode,
                                g.lpq, g.m_pad, g.splits, k, m, n, (const uint16_t *)q, (const uint16_t *)r, lists,
-                               counts, qnorm, scal, index_base, keys, amb_list);
+                               counts, qnorm, scal, index_base, keys, amb_list, multi_list);
         else
             hipLaunchKernelGGL(finalize_wave_kernel<float>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, mode, g.lpq, g.m_pad,
                                g.splits, k, m, n, (const float *)q, (const float *)r, lists, counts, qnorm, scal,
-                               index_base, keys, amb_list);
+                               index_base, keys, amb_list, multi_list);
         NNS_HIP(hipGetLastError());
         return NNS_OK;
     }
     if (data_bf16)
         hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(divup(g.m_pad / (64 / g.lpq), 4)), dim3(256), 0, st, g.kt, mode, g.lpq, g.m_pad,
                            g.splits, k, m, n, (const uint16_t *)q, (const uint16_t *)r, lists, counts, qnorm,
-                           scal, index_base, keys, amb_list);
+                           scal, index_base, keys, amb_list, multi_list);
     else
         hipLaunchKernelGGL(finalize_kernel<float>, dim3(divup(g.m_pad / (64 / g.lpq), 4)), dim3(256), 0, st, g.kt, mode, g.lpq, g.m_pad,
                            g.splits, k, m, n, (const float *)q, (const float *)r, lists, counts, qnorm, scal,
-                           index_base, keys, amb_list);
+                           index_base, keys, amb_list, multi_list);
     NNS_HIP(hipGetLastError());
     return NNS_OK;
 }

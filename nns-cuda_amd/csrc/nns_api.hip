@@ -39,6 +39,8 @@ static size_t img_row_bytes(const FilterGeom &g)
 // below this many queries the AUTO path skips the MFMA filter (and, in the whole-call
 // entry points, its ref pre-pass too)
 static const int kTinyM = 64;
+// deepest dimensionality the MFMA filter tiles (bf16 operands; fp32 operands: 256)
+static const int kMaxFilterK = 512;
 
 enum { EV_BEGIN = 0, EV_QPREP, EV_FILTER, EV_FINAL, EV_RERANK, EV_END, EV_R0, EV_R1, EV_COUNT };
 static const int kEvRing = 32;
@@ -72,6 +74,7 @@ struct nns_index {
     int *counts = nullptr;        // [splits][m_pad/32][64]
     size_t lists_cap = 0;         // in lane-lists
     int *amb_list = nullptr;
+    int *multi_list = nullptr;    // queries K5 decided among several candidates (nns_index_near_ties)
 
     // exact path: per-split partial keys of K1a
     nns_key *exact_ws = nullptr;
@@ -168,6 +171,7 @@ int nns_index_destroy(nns_index *ix)
     pool_free(ix->lists);
     pool_free(ix->counts);
     pool_free(ix->amb_list);
+    pool_free(ix->multi_list);
     pool_free(ix->exact_ws);
     if (ix->ev_valid)
         for (int r = 0; r < kEvRing; ++r)
@@ -200,6 +204,31 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
     ix->flags = flags;
     ix->r_dev = r_dev;
     ix->bf16 = bf16;
+    ix->profile = (flags & NNS_PROFILE) != 0;
+    if (flags & NNS_FILTER_BF16) {
+        if (bf16) {
+            set_error("NNS_FILTER_BF16 applies to fp32 points (bf16 points already use the bf16 filter)");
+            delete ix;   // nothing allocated or enqueued yet
+            return NNS_ERR_INVALID;
+        }
+        ix->mixed = true;
+    }
+
+    // fp32 points beyond the deepest fp32 tile (256): AUTO takes the bf16-operand filter — the re-rank makes
+    // the result bits identical, and the alternative is the VALU scan
+    if ((flags & NNS_PATH_MASK) == NNS_PATH_AUTO && !bf16 && k > 256 && k <= kMaxFilterK) ix->mixed = true;
+    const int kmax = (bf16 || ix->mixed) ? kMaxFilterK : 256;   // deepest tile of the MFMA filter
+    int path = flags & NNS_PATH_MASK;
+    // crossover: from k = 8 the MFMA filter (KT = 16 / 32 tile) beats 3k VALU ops per pair; bf16 tiles
+    // are at least 128 deep, so they only pay from k = 32
+    const int kmin = bf16 ? 32 : 8;
+    if (path == NNS_PATH_AUTO) path = (k >= (ix->mixed ? 32 : kmin) && k <= kmax) ? NNS_PATH_MFMA : NNS_PATH_EXACT;
+    if (path == NNS_PATH_MFMA && k > kmax) {
+        set_error("NNS_PATH_MFMA: k = %d > %d is not tiled (use NNS_PATH_AUTO/EXACT)", k, kmax);
+        delete ix;   // nothing allocated or enqueued yet
+        return NNS_ERR_UNSUPPORTED;
+    }
+    ix->path = path;
     if (flags & NNS_REFS_SOA) {
         // dimension-major refs: one transpose into a point-major copy the index owns
         const size_t esz = bf16 ? sizeof(uint16_t) : sizeof(float);
@@ -216,31 +245,6 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
         }
         ix->r_dev = ix->r_own;
     }
-    ix->profile = (flags & NNS_PROFILE) != 0;
-    if (flags & NNS_FILTER_BF16) {
-        if (bf16) {
-            set_error("NNS_FILTER_BF16 applies to fp32 points (bf16 points already use the bf16 filter)");
-            nns_index_destroy(ix);
-            return NNS_ERR_INVALID;
-        }
-        ix->mixed = true;
-    }
-
-    // fp32 points beyond the deepest fp32 tile (256): AUTO takes the bf16-operand filter (512 deep) — the
-    // re-rank makes the result bits identical, and the alternative is the VALU scan
-    if ((flags & NNS_PATH_MASK) == NNS_PATH_AUTO && !bf16 && k > 256 && k <= 512) ix->mixed = true;
-    const int kmax = (bf16 || ix->mixed) ? 512 : 256;   // deepest tile of the MFMA filter
-    int path = flags & NNS_PATH_MASK;
-    // crossover: from k = 8 the MFMA filter (KT = 32 tile) beats 3k VALU ops per pair; bf16 tiles
-    // are 256 deep, so they only pay from k = 32
-    const int kmin = bf16 ? 32 : 8;
-    if (path == NNS_PATH_AUTO) path = (k >= (ix->mixed ? 32 : kmin) && k <= kmax) ? NNS_PATH_MFMA : NNS_PATH_EXACT;
-    if (path == NNS_PATH_MFMA && k > kmax) {
-        set_error("NNS_PATH_MFMA: k = %d > %d is not tiled yet (use NNS_PATH_AUTO/EXACT)", k, kmax);
-        delete ix;
-        return NNS_ERR_UNSUPPORTED;
-    }
-    ix->path = path;
 
     int rc = NNS_OK;
     do {
@@ -317,6 +321,10 @@ int nns_index_refresh(nns_index *ix, void *stream)
     if (ix->path != NNS_PATH_MFMA) return NNS_OK;
     if (ix->profile) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_R0], st);
     NNS_TRY(prep_refs(ix, st));
+    // The new values may or may not void the error bound (NaN / INF / huge); refresh stays asynchronous,
+    // so the next search runs the filter and K5 decides on the device (finalize.hip re-checks K2's max-|v|
+    // word and sends every query to the exact scan if it must).  nns_index_stats() re-latches the flag.
+    ix->refs_bad = false;
     if (ix->profile) {
         (void)hipEventRecord(ix->evr[ix->ev_slot][EV_R1], st);
         ix->ev_refreshed[ix->ev_slot] = true;
@@ -336,13 +344,16 @@ static int ensure_query_ws(nns_index *ix, int m)
         pool_free(ix->qimg);
         pool_free(ix->qnorm);
         pool_free(ix->amb_list);
+        pool_free(ix->multi_list);
         ix->qimg = nullptr;
         ix->qnorm = nullptr;
         ix->amb_list = nullptr;
+        ix->multi_list = nullptr;
         ix->m_cap = 0;
         if (pool_alloc(&ix->qimg, (size_t)gq.m_pad * img_row_bytes(gq)) != hipSuccess ||
             pool_alloc(&ix->qnorm, (size_t)gq.m_pad * sizeof(float)) != hipSuccess ||
-            pool_alloc(&ix->amb_list, (size_t)gq.m_pad * sizeof(int)) != hipSuccess) {
+            pool_alloc(&ix->amb_list, (size_t)gq.m_pad * sizeof(int)) != hipSuccess ||
+            pool_alloc(&ix->multi_list, (size_t)gq.m_pad * sizeof(int)) != hipSuccess) {
             set_error("query workspace allocation failed (m_pad=%d)", gq.m_pad);
             return NNS_ERR_NOMEM;
         }
@@ -424,9 +435,10 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
     const FilterGeom &g = ix->geom;
     if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_BEGIN], st);
     // reset the per-search scalars (q max-abs, ambiguous count); keep the ref-side ones
-    static_assert(offsetof(DevScalars, amb_count) == offsetof(DevScalars, q_maxabs_bits) + sizeof(unsigned),
+    static_assert(offsetof(DevScalars, amb_count) == offsetof(DevScalars, q_maxabs_bits) + sizeof(unsigned) &&
+                      offsetof(DevScalars, multi_count) == offsetof(DevScalars, amb_count) + sizeof(int),
                   "per-search scalars must be adjacent");
-    NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned) + sizeof(int), st));
+    NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned) + 2 * sizeof(int), st));
     if (bf16)
         NNS_TRY(launch_prep_image_bf16((NNS_BF16_TILE16 && g.kt != 512) ? 1 : 0, g.kt, ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
                                        nullptr, &ix->scal->q_maxabs_bits, st));
@@ -436,6 +448,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
     if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_QPREP], st);
     NNS_TRY(launch_filter(g, ix->qimg, ix->rimg, ix->rnorm, ix->qnorm, ix->scal, ix->lists, ix->counts, st));
     if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_FILTER], st);
+#ifdef NNS_DIAG
     // tuning diagnostic for ablated filter builds (-DNNS_FILTER_ABLATE: empty candidate lists would
     // send every query to the exact scan): stop after the filter; the keys are NOT results
     static const bool filter_only = getenv("NNS_DIAG_FILTER_ONLY") != nullptr;
@@ -451,8 +464,9 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
         profile_advance(ix, NNS_PATH_MFMA);
         return NNS_OK;
     }
+#endif
     NNS_TRY(launch_finalize(g, ix->k, m, ix->n, q_dev, ix->r_dev, ix->lists, ix->counts, ix->qnorm,
-                            ix->scal, ix->base, keys_dev, ix->amb_list, st));
+                            ix->scal, ix->base, keys_dev, ix->amb_list, ix->multi_list, st));
     if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_FINAL], st);
     if (bf16)
         NNS_TRY(launch_exact_listed_bf16(ix->k, ix->n, (const uint16_t *)q_dev, (const uint16_t *)ix->r_dev,
@@ -494,7 +508,9 @@ int nns_index_stats(nns_index *ix, nns_stats *out)
         DevScalars h{};
         NNS_HIP(hipMemcpy(&h, ix->scal, sizeof(h), hipMemcpyDeviceToHost));
         out->ambiguous = ix->searched && ix->last_path == NNS_PATH_MFMA ? h.amb_count : 0;
-        if (h.q_maxabs_bits >= 0x5BB1A2BCu) out->nonfinite = 1;
+        out->multi_candidate = ix->searched && ix->last_path == NNS_PATH_MFMA ? h.multi_count : 0;
+        ix->refs_bad = h.r_maxabs_bits >= 0x5BB1A2BCu;   // (re-)latch: refs that void the bound go straight to K1
+        if (ix->refs_bad || h.q_maxabs_bits >= 0x5BB1A2BCu) out->nonfinite = 1;
     }
     if (ix->profile && ix->ev_valid) {
         NNS_HIP(hipDeviceSynchronize());
@@ -543,6 +559,34 @@ int nns_index_stats(nns_index *ix, nns_stats *out)
         ix->ev_count = 0;
         (void)hipGetLastError();
     }
+    return NNS_OK;
+}
+
+int nns_index_near_ties(nns_index *ix, int *ids_out, int cap, int *count_out)
+{
+    if (!ix || !count_out || cap < 0 || (cap > 0 && !ids_out)) {
+        set_error("nns_index_near_ties: bad arguments");
+        return NNS_ERR_INVALID;
+    }
+    *count_out = 0;
+    NNS_TRY(ensure_device_ok(ix->device));
+    if (ix->path != NNS_PATH_MFMA || !ix->searched || ix->last_path != NNS_PATH_MFMA) return NNS_OK;
+    NNS_HIP(hipDeviceSynchronize());
+    DevScalars h{};
+    NNS_HIP(hipMemcpy(&h, ix->scal, sizeof(h), hipMemcpyDeviceToHost));
+    *count_out = h.multi_count;
+    const int take = h.multi_count < cap ? h.multi_count : cap;
+    if (take > 0) NNS_HIP(hipMemcpy(ids_out, ix->multi_list, (size_t)take * sizeof(int), hipMemcpyDeviceToHost));
+    return NNS_OK;
+}
+
+int nns_tau_consts(int kt, float qnorm2, float ymax2, int mode, float *out3)
+{
+    if (kt <= 0 || mode < 0 || mode > 2 || !out3) return NNS_ERR_INVALID;
+    const TauConsts t = tau_consts(kt, qnorm2, ymax2, mode);
+    out3[0] = t.c0;
+    out3[1] = t.c1;
+    out3[2] = t.x2;
     return NNS_OK;
 }
 

@@ -159,10 +159,11 @@ __host__ __device__ inline float tau_of(const TauConsts &t, float a)
 struct DevScalars {
     unsigned r_maxabs_bits;  // max |r| bits (NaN/INF/huge detection)
     unsigned ymax2_bits;     // max centred squared norm over refs
-    // the two per-search words are adjacent: one 8-byte memset resets them
+    // the three per-search words are adjacent: one 12-byte memset resets them
     unsigned q_maxabs_bits;  // max |q| bits
-    int amb_count;           // number of ambiguous queries
-    unsigned pad[4];
+    int amb_count;           // number of ambiguous queries (sent to the exact scan)
+    int multi_count;         // number of queries K5 decided among MORE THAN ONE candidate within tau
+    unsigned pad[3];
 };
 
 // ---- launchers (each .hip file owns its kernels) --------------------------------
@@ -220,6 +221,6 @@ int launch_mfma_selftest(int kt, int bf16, const float *a, const float *b, const
 int launch_finalize(const FilterGeom &g, int k, int m, int n, const void *q, const void *r,
                     const CandEntry *lists, const int *counts, const float *qnorm,
                     DevScalars *scal, int64_t index_base, nns_key *keys, int *amb_list,
-                    hipStream_t st);
+                    int *multi_list, hipStream_t st);
 
 }  // namespace nns

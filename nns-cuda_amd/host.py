@@ -39,8 +39,11 @@ ABI_SYMBOLS = (
     "nns_keys_unpack", "nns_fill_uniform", "nns_device_count", "nns_strerror",
     "nns_last_error", "nns_version", "nns_selftest_mfma",
     "nns_index_create_bf16", "nns_index_search_bf16", "nns_search_bf16_ex", "nns_search_f32_multi",
-    "nns_trim", "nns_warmup",
+    "nns_trim", "nns_warmup", "nns_shutdown", "nns_search_bf16_multi",
+    "nns_index_near_ties", "nns_tau_consts",
+    "nns_comm_unique_id", "nns_comm_create", "nns_comm_size", "nns_comm_allreduce_min", "nns_comm_destroy",
 )
+NNS_COMM_ID_BYTES = 128
 
 
 class NNSError(RuntimeError):
@@ -58,7 +61,7 @@ class nns_stats(ctypes.Structure):
         ("prep_refs_ms", ctypes.c_float), ("prep_queries_ms", ctypes.c_float),
         ("filter_ms", ctypes.c_float), ("finalize_ms", ctypes.c_float),
         ("rerank_ms", ctypes.c_float), ("exact_ms", ctypes.c_float),
-        ("total_ms", ctypes.c_float),
+        ("total_ms", ctypes.c_float), ("multi_candidate", ctypes.c_int),
     ]
 
     def asdict(self):
@@ -86,10 +89,19 @@ def _load() -> ctypes.CDLL:
     lib.nns_index_search_bf16.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
     lib.nns_search_bf16_ex.argtypes = lib.nns_search_f32_ex.argtypes
     lib.nns_search_f32_multi.argtypes = [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_u]
+    lib.nns_search_bf16_multi.argtypes = lib.nns_search_f32_multi.argtypes
+    lib.nns_comm_unique_id.argtypes = [c_vp, c_sz]
+    lib.nns_comm_create.argtypes = [ctypes.POINTER(c_vp), c_vp, c_sz, c_int, c_int, c_int]
+    lib.nns_comm_size.argtypes = [c_vp]
+    lib.nns_comm_allreduce_min.argtypes = [c_vp, c_vp, c_int, c_vp]
+    lib.nns_comm_destroy.argtypes = [c_vp]
+    lib.nns_shutdown.argtypes = []
     lib.nns_index_destroy.argtypes = [c_vp]
     lib.nns_index_refresh.argtypes = [c_vp, c_vp]
     lib.nns_index_search.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
     lib.nns_index_stats.argtypes = [c_vp, ctypes.POINTER(nns_stats)]
+    lib.nns_index_near_ties.argtypes = [c_vp, c_vp, c_int, ctypes.POINTER(c_int)]
+    lib.nns_tau_consts.argtypes = [c_int, ctypes.c_float, ctypes.c_float, c_int, c_vp]
     lib.nns_keys_min.argtypes = [c_vp, c_vp, c_int, c_vp]
     lib.nns_keys_unpack.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
     lib.nns_fill_uniform.argtypes = [c_vp, c_sz, c_u64, c_u64, c_vp]
@@ -130,6 +142,13 @@ def selftest_mfma(a: np.ndarray, b: np.ndarray, c0: np.ndarray, bf16: bool = Fal
     _check(lib.nns_selftest_mfma(a.shape[1], int(bf16), a.ctypes.data, b.ctypes.data, c0.ctypes.data, out.ctypes.data),
            "nns_selftest_mfma")
     return out
+
+
+def tau_consts(kt: int, qnorm2: float, ymax2: float, mode: int):
+    """(c0, c1, x2) of the proof margin tau(a) = c0 + c1 * max(a + x2, 0) (nns_tau_consts)."""
+    out = np.empty(3, np.float32)
+    _check(lib.nns_tau_consts(kt, qnorm2, ymax2, mode, out.ctypes.data), "nns_tau_consts")
+    return float(out[0]), float(out[1]), float(out[2])
 
 
 def device_count() -> int:
@@ -185,22 +204,29 @@ def search(query_points, reference_points, *, return_distances: bool = False, sh
 
 
 def search_multi(query_points, reference_points, *, num_devices: int = 0, return_distances: bool = False,
-                 path: str = "auto", virtual: bool = False):
+                 path: str = "auto", virtual: bool = False, refs_soa: bool = False, bf16: bool = False):
     """The V8/V9 analogue: refs sharded over `num_devices` GPUs of this process (0 = all),
     per-GPU keys combined with one RCCL min all-reduce.  `virtual` lets a 1-GPU box rehearse
-    more shards than it has GPUs (host-side key merge)."""
-    q = _as_f32(query_points, "query_points")
-    r = _as_f32(reference_points, "reference_points")
-    if q.shape[1] != r.shape[1]:
+    more shards than it has GPUs (host-side key merge).  `bf16`: the arrays hold bf16 bit
+    patterns (uint16); `refs_soa`: reference_points is dimension-major [k][n]."""
+    if bf16:
+        q = np.ascontiguousarray(query_points, dtype=np.uint16)
+        r = np.ascontiguousarray(reference_points, dtype=np.uint16)
+        if q.ndim != 2 or r.ndim != 2:
+            raise ValueError("bf16 point sets must be 2-D arrays of bit patterns")
+    else:
+        q = _as_f32(query_points, "query_points")
+        r = _as_f32(reference_points, "reference_points")
+    if q.shape[1] != (r.shape[0] if refs_soa else r.shape[1]):
         raise ValueError("query and reference dimensionality differ")
     m, k = q.shape
-    n = r.shape[0]
+    n = r.shape[1] if refs_soa else r.shape[0]
     idx = np.empty(m, dtype=np.int32)
     dist = np.empty(m, dtype=np.float32) if return_distances else None
-    flags = _PATHS[path] | (NNS_MULTI_VIRTUAL if virtual else 0)
-    _check(lib.nns_search_f32_multi(k, m, n, q.ctypes.data, r.ctypes.data, idx.ctypes.data,
-                                    dist.ctypes.data if dist is not None else None, num_devices, flags),
-           "nns_search_f32_multi")
+    flags = _PATHS[path] | (NNS_MULTI_VIRTUAL if virtual else 0) | (NNS_REFS_SOA if refs_soa else 0)
+    fn = lib.nns_search_bf16_multi if bf16 else lib.nns_search_f32_multi
+    _check(fn(k, m, n, q.ctypes.data, r.ctypes.data, idx.ctypes.data,
+              dist.ctypes.data if dist is not None else None, num_devices, flags), "nns_search_multi")
     return (idx, dist) if return_distances else idx
 
 
@@ -297,6 +323,14 @@ class Index:
         _check(lib.nns_index_stats(self._h, ctypes.byref(st)), "nns_index_stats")
         return st.asdict()
 
+    def near_ties(self) -> np.ndarray:
+        """Query numbers of the last search that K5 decided among > 1 candidates within tau."""
+        cnt = ctypes.c_int(0)
+        _check(lib.nns_index_near_ties(self._h, None, 0, ctypes.byref(cnt)), "nns_index_near_ties")
+        ids = np.empty(max(cnt.value, 1), dtype=np.int32)
+        _check(lib.nns_index_near_ties(self._h, ids.ctypes.data, cnt.value, ctypes.byref(cnt)), "nns_index_near_ties")
+        return np.sort(ids[:cnt.value])
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             lib.nns_index_destroy(self._h)
@@ -343,10 +377,58 @@ def shard_range(n: int, shards: int, rank: int) -> Tuple[int, int]:
     return beg, cnt
 
 
-def allreduce_min_keys(keys, group=None) -> None:
-    """The cross-GPU exchange: ONE min all-reduce of the packed keys (RCCL over xGMI
-    when the process group is 'nccl'; gloo in CPU tests).  Keys are < 2^63, so the
-    signed int64 order torch reduces in is the unsigned key order."""
+def comm_unique_id() -> bytes:
+    """nns_comm_unique_id: the 128 bytes rank 0 hands to every rank (RCCL's ncclUniqueId)."""
+    buf = ctypes.create_string_buffer(NNS_COMM_ID_BYTES)
+    _check(lib.nns_comm_unique_id(buf, NNS_COMM_ID_BYTES), "nns_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """One rank of the one-process-per-GPU exchange (nns_comm): ONE
+    ncclAllReduce(ncclUint64, ncclMin) of the packed keys per search, issued by the library —
+    the same call site nns_search_f32_multi uses.  Creation is collective over all ranks."""
+
+    def __init__(self, unique_id: bytes, nranks: int, rank: int, device: int):
+        h = ctypes.c_void_p()
+        _check(lib.nns_comm_create(ctypes.byref(h), unique_id, len(unique_id), nranks, rank, device),
+               "nns_comm_create")
+        self._h = h
+        self.nranks, self.rank, self.device = nranks, rank, device
+
+    def size(self) -> int:
+        return lib.nns_comm_size(self._h)
+
+    def allreduce_min(self, keys, stream=None) -> None:
+        _check(lib.nns_comm_allreduce_min(self._h, keys.data_ptr(), keys.numel(), _stream_ptr(stream)),
+               "nns_comm_allreduce_min")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib.nns_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shutdown() -> None:
+    """nns_shutdown: destroy the cached communicators of search_multi, trim the pool."""
+    _check(lib.nns_shutdown(), "nns_shutdown")
+
+
+def allreduce_min_keys(keys, group=None, comm: Optional[Comm] = None) -> None:
+    """The cross-GPU exchange: ONE min all-reduce of the packed keys.  With `comm` the library
+    issues it itself (ncclAllReduce(uint64, min) over xGMI, nns_comm_allreduce_min); without,
+    it goes through torch.distributed (RCCL when the process group is 'nccl'; gloo in CPU
+    tests).  Keys are < 2^63, so the signed int64 order torch reduces in is the unsigned key
+    order and both give the same bits."""
+    if comm is not None:
+        comm.allreduce_min(keys)
+        return
     import torch.distributed as dist
     if keys.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsal on a box without one GPU per rank: same operator through the host

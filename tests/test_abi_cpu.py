@@ -56,6 +56,19 @@ def test_fails_loudly_without_device(pkg):
         pkg.search(q, q)
 
 
+def test_shipped_library_has_no_diagnostic_switches(pkg):
+    """The product build carries no environment variable that changes results (the timing
+    diagnostics NNS_DIAG_FILTER_ONLY / NNS_FILTER_CLOCK exist only under -DNNS_DIAG)."""
+    blob = open(pkg.LIB_PATH, "rb").read()
+    for name in (b"NNS_DIAG_FILTER_ONLY", b"NNS_FILTER_CLOCK", b"NNS_FILTER_ABLATE"):
+        assert name not in blob, name
+    # the only environment variable the library reads: the pool cap
+    # (other NNS_* strings are names of include/nns.h flags quoted in error messages)
+    names = {n for n in re.findall(rb"NNS_[A-Z_]{3,}", blob)
+             if not re.match(rb"NNS_(PATH_|FILTER_BF|REFS_SOA|COMM_ID_BYTES|MULTI_VIRTUAL|ERR_|KEY_NONE)", n)}
+    assert names == {b"NNS_POOL_BYTES"}, names
+
+
 def test_shard_range_is_reference_split(pkg):
     # core.cu:781-791: contiguous ceil(n/G), last takes the remainder
     assert [pkg.shard_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 3), (6, 3), (9, 1)]

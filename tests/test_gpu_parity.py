@@ -59,25 +59,94 @@ def test_mfma_is_an_fmaf_chain(pkg, orc):
                 assert out[i, j].view(np.uint32) == want.view(np.uint32), (kt, i, j)
 
 
+def _bf16_model_cases(rng, kt):
+    """(name, a[32][kt], b[32][kt]) operand families for the accumulate-model test: a = refs (x -2),
+    b = queries.  fp32 values; the test rounds them to bf16."""
+    u01 = lambda: rng.random((32, kt), dtype=np.float32)                       # noqa: E731
+    cases = [("uniform", u01() * -2.0, u01()),
+             ("same_sign_big", (1.0 + u01()) * -2.0, 1.0 + u01()),             # every product negative: no cancellation
+             ("same_sign_pos", (1.0 + u01()) * 2.0, 1.0 + u01()),
+             ("cancelling", (u01() - 0.5) * -2.0, u01() - 0.5),               # products of both signs, sum ~ 0
+             ("centred_small", (u01() - 0.5) * -2e-3, (u01() - 0.5) * 1e-3)]
+    e = rng.integers(-12, 12, (32, kt))
+    cases.append(("wide_exponents", (np.ldexp(1.0 + u01(), e) * -2.0).astype(np.float32),
+                  np.ldexp(1.0 + u01(), rng.integers(-12, 12, (32, kt))).astype(np.float32)))
+    # one huge term first / last among tiny ones: tests the order-independence assumption
+    big_first = u01() * 1e-3
+    big_first[:, 0] = 300.0
+    big_last = u01() * 1e-3
+    big_last[:, -1] = 300.0
+    cases.append(("big_first", big_first * -2.0, big_first.copy()))
+    cases.append(("big_last", big_last * -2.0, big_last.copy()))
+    return cases
+
+
 @pytest.mark.parametrize("shape", [2, 1])
-def test_bf16_mfma_error_model(pkg, orc, shape):
-    """bf16 MFMA (fp32 accumulate) vs fp64 on bf16-representable data: the error must stay well
-    inside the 2u-per-add model tau assumes for the bf16 path.  shape 2 = the filter's
-    v_mfma_f32_16x16x32_bf16 with the operand / result lane mapping K2's images and the filter's
-    epilogue assume (a wrong mapping shows up as O(1) errors here); shape 1 = 32x32x16."""
-    rng = np.random.default_rng(2)
-    kt = 256
-    a = orc.round_bf16((rng.random((32, kt), dtype=np.float32)) * -2.0)
-    b = orc.round_bf16(rng.random((32, kt), dtype=np.float32))
-    c0 = (a.astype(np.float64) ** 2).sum(1).astype(np.float32) / 4
-    out = pkg.selftest_mfma(a, b, c0, bf16=shape)
-    exact = c0.astype(np.float64)[:, None] + a.astype(np.float64) @ b.astype(np.float64).T
-    mag = np.abs(c0.astype(np.float64))[:, None] + np.abs(a.astype(np.float64)) @ np.abs(b.astype(np.float64)).T
+@pytest.mark.parametrize("kt", [128, 256, 512])
+def test_bf16_mfma_error_model(pkg, orc, shape, kt):
+    """The bf16 MFMA's accumulation (fp32 accumulate, order and rounding undocumented) against fp64 on
+    bf16-representable operands, at EVERY depth the product runs bf16 tiles (128 / 256 / 512), for both
+    MFMA shapes (2 = v_mfma_f32_16x16x32_bf16 with the operand / result lane mapping K2's images and the
+    filter's epilogue assume — a wrong mapping shows up as O(1) errors here; 1 = 32x32x16), several seeds
+    and adversarial magnitudes.  The proof margin tau assumes 2u per add (nns_internal.h tau_consts,
+    mode 1): the test FAILS if the hardware error of any output exceeds 1/4 of that e3 bound."""
     u = 2.0 ** -24
-    bound = 2 * (kt + kt // 16 + 2) * u * mag
-    err = np.abs(out.astype(np.float64) - exact)
-    assert (err <= bound).all()
-    assert err.max() <= 0.25 * bound.max(), (err.max(), bound.max())   # comfortable slack
+    worst = 0.0
+    for seed in (2, 3, 5, 8):
+        rng = np.random.default_rng(seed * 1000 + kt + shape)
+        for name, a32, b32 in _bf16_model_cases(rng, kt):
+            a = orc.round_bf16(a32)
+            b = orc.round_bf16(b32)
+            a64, b64 = a.astype(np.float64), b.astype(np.float64)
+            c0 = ((a64 / 2) ** 2).sum(1).astype(np.float32)           # the refs' squared norms (a = -2 y)
+            out = pkg.selftest_mfma(a, b, c0, bf16=shape)
+            exact = c0.astype(np.float64)[:, None] + a64 @ b64.T
+            err = np.abs(out.astype(np.float64) - exact)                # [ref i][query j]
+            # the model's bound for query j: e3 = (c0_tau / (2 + c1)) / 1.001 with X^2 = |x_j|^2, Y^2 = max |y|^2
+            y2max = float(((a64 / 2) ** 2).sum(1).max())
+            for j in range(32):
+                x2 = float((b64[j] ** 2).sum())
+                c0t, c1t, _ = pkg.tau_consts(kt, x2, y2max, 1)
+                e3 = c0t / (2.0 + c1t) / 1.001
+                ratio = err[:, j].max() / e3
+                worst = max(worst, ratio)
+                assert ratio <= 0.25, (name, seed, kt, shape, j, err[:, j].max(), e3)
+            # and elementwise inside the plain 2u-per-add bound on the actual magnitudes
+            mag = np.abs(c0.astype(np.float64))[:, None] + np.abs(a64) @ np.abs(b64).T
+            assert (err <= 2 * (kt + kt // 16 + 2) * u * mag).all(), (name, seed, kt, shape)
+    print(f"bf16 MFMA shape {shape} kt {kt}: worst error / e3 bound = {worst:.4f}")
+
+
+@pytest.mark.parametrize("kt", [128, 256, 512])
+def test_bf16_operand_rounding_model_mode2(pkg, orc, kt):
+    """tau mode 2 (fp32 points, operands rounded to bf16, NNS_FILTER_BF16): the filter's score error
+    against the UNROUNDED fp32 values — rounding bound 2^-6 (1 + 2^-8) |x'||y'| plus the accumulate
+    model — must hold, also on data placed at bf16 rounding midpoints with every product of the same
+    sign (where the rounding bound is nearly attained; random data sits ~1/sqrt(k) below it)."""
+    for seed in (1, 4):
+        rng = np.random.default_rng(seed * 77 + kt)
+        fams = [("uniform", rng.random((32, kt), dtype=np.float32) - 0.5, rng.random((32, kt), dtype=np.float32) - 0.5)]
+        # just below a rounding midpoint: 1 + 2^-8 - 2^-20 rounds DOWN to 1 (relative error ~2^-8), same sign
+        mid = np.float32(1.0 + 2.0 ** -8 - 2.0 ** -20)
+        sc = np.ldexp(np.float32(1.0), rng.integers(-3, 3, (32, 1))).astype(np.float32)
+        fams.append(("midpoints_same_sign", np.full((32, kt), mid, np.float32) * sc, np.full((32, kt), mid, np.float32)))
+        fams.append(("midpoints_up", np.full((32, kt), np.float32(1.0 + 2.0 ** -8 + 2.0 ** -20)) * sc,
+                     np.full((32, kt), np.float32(1.0 + 2.0 ** -8 + 2.0 ** -20))))
+        for name, y, x in fams:
+            a_true = (-2.0 * y).astype(np.float32)                      # exact scaling
+            a, b = orc.round_bf16(a_true), orc.round_bf16(x)            # what K2 writes (RNE)
+            c0 = (y.astype(np.float64) ** 2).sum(1).astype(np.float32)
+            out = pkg.selftest_mfma(a, b, c0, bf16=2 if kt != 512 else 1)
+            exact = c0.astype(np.float64)[:, None] + a_true.astype(np.float64) @ x.astype(np.float64).T
+            err = np.abs(out.astype(np.float64) - exact)
+            y2max = float((y.astype(np.float64) ** 2).sum(1).max())
+            for j in range(32):
+                x2 = float((x[j].astype(np.float64) ** 2).sum())
+                c0t, c1t, _ = pkg.tau_consts(kt, x2, y2max, 2)
+                bound = c0t / (2.0 + c1t) / 1.001                       # e3 + e2 of mode 2
+                assert err[:, j].max() <= bound, (name, seed, kt, j, err[:, j].max(), bound)
+                if name == "uniform":
+                    assert err[:, j].max() <= 0.25 * bound
 
 
 def test_golden_recipe_samples(pkg, orc, golden_dir):
@@ -272,9 +341,14 @@ def test_headline_shape_properties(pkg, orc):
     assert np.array_equal(idx_h[planted_q.cpu().numpy()], planted_r.cpu().numpy().astype(np.int32))
     assert (dist_h[planted_q.cpu().numpy()] == 0).all()
     assert idx_h.min() >= 0 and idx_h.max() < n
-    # sampled queries against the oracle over ALL refs
+    # SURVEY 8d's gate: >= 1024 RANDOM queries + EVERY query whose filter margin was below tau (K5 chose
+    # among several candidates: nns_index_near_ties), against the oracle over ALL refs (queries sent to
+    # the exact scan — none at this shape — get V0's arithmetic over all refs by construction)
     rh = r.cpu().numpy()
-    sel = np.random.default_rng(0).choice(m, 48, replace=False)
+    near = ix.near_ties()
+    assert near.size == st["multi_candidate"] and near.size < m // 4, (near.size, st)
+    sel = np.unique(np.concatenate([np.random.default_rng(0).choice(m, 1024, replace=False), near]))
+    print(f"C3: {near.size} near-tie queries, {st['ambiguous']} exact-scan queries, checking {sel.size} queries in full")
     qh = q[torch.from_numpy(sel).cuda()].cpu().numpy()
     want_idx, want_dist = orc.v0_search(qh, rh, threads=16)
     assert np.array_equal(idx_h[sel], want_idx)
@@ -424,7 +498,7 @@ def test_c2_shape_all_queries(pkg, orc):
     assert np.array_equal(idx, want_idx) and np.array_equal(_bits(dist), _bits(want_dist))
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1100)
 def test_c4_shape_on_one_gpu_by_shards(pkg, orc):
     """BASELINE config C4 (65536 x 8388608 x 128, refs sharded 8 ways) rehearsed on ONE GPU: the 8
     shards are searched one after another with their index_base and merged with nns_keys_min —
@@ -438,6 +512,7 @@ def test_c4_shape_on_one_gpu_by_shards(pkg, orc):
     r_host = np.empty((n, k), dtype=np.float32)
     planted_q = np.arange(shards * 16) * 401
     planted_r = np.empty(shards * 16, dtype=np.int64)
+    near_all = []
     for s in range(shards):
         r = torch.empty((per, k), dtype=torch.float32, device="cuda")
         pkg.fill_uniform(r, 1000, m * k + s * per * k)       # the bench's global ref stream
@@ -454,6 +529,7 @@ def test_c4_shape_on_one_gpu_by_shards(pkg, orc):
         else:
             pkg.keys_min(keys, ks)
         torch.cuda.synchronize()
+        near_all.append(ix.near_ties())       # this shard's queries decided among several candidates
         ix.close()
         del r
     idx, dist = pkg.keys_unpack(keys, return_distances=True)
@@ -461,7 +537,11 @@ def test_c4_shape_on_one_gpu_by_shards(pkg, orc):
     assert idx_h.min() >= 0 and idx_h.max() < n
     assert np.array_equal(idx_h[planted_q], planted_r.astype(np.int32))
     assert (dist_h[planted_q] == 0).all()
-    sel = np.random.default_rng(4).choice(m, 24, replace=False)
+    # >= 1024 random queries + every near-tie query of any shard, against the oracle over all 8M refs
+    near = np.unique(np.concatenate(near_all))
+    assert near.size < m // 2
+    sel = np.unique(np.concatenate([np.random.default_rng(4).choice(m, 1024, replace=False), near]))
+    print(f"C4: {near.size} near-tie queries over the 8 shards, checking {sel.size} queries in full")
     want_idx, want_dist = orc.v0_search(q[torch.from_numpy(sel).cuda()].cpu().numpy(), r_host, threads=16)
     assert np.array_equal(idx_h[sel], want_idx)
     assert np.array_equal(_bits(dist_h[sel]), _bits(want_dist))
@@ -530,6 +610,7 @@ def test_workspace_pool_reuse_and_trim(pkg, orc):
         assert np.array_equal(pkg.search(q, r), w)
 
 
+@pytest.mark.timeout(1100)
 def test_c5_headline_shape_properties(pkg, orc):
     """BASELINE C5 (131072 x 2097152 x 256 bf16 points) at full size through the 16x16x32 bf16
     filter: planted exact matches, sampled queries against the oracle (V0 arithmetic on the bf16
@@ -566,7 +647,10 @@ def test_c5_headline_shape_properties(pkg, orc):
     rh = rb.view(torch.int16).cpu().numpy().view(np.uint16)
     rw = (rh.astype(np.uint32) << 16).view(np.float32)
     del rh
-    sel = np.random.default_rng(5).choice(m, 24, replace=False)
+    near = ix.near_ties()
+    assert near.size == st["multi_candidate"] and near.size < m // 4, (near.size, st)
+    sel = np.unique(np.concatenate([np.random.default_rng(5).choice(m, 1024, replace=False), near]))
+    print(f"C5: {near.size} near-tie queries, {st['ambiguous']} exact-scan queries, checking {sel.size} queries in full")
     qsel = qb[torch.from_numpy(sel).cuda()].view(torch.int16).cpu().numpy().view(np.uint16)
     qw = (qsel.astype(np.uint32) << 16).view(np.float32)
     want_idx, want_dist = orc.v0_search(qw, rw, threads=16)
@@ -830,3 +914,130 @@ def test_short_randomised_sweep():
     last = out.stdout.strip().splitlines()[-1]
     assert last.startswith("fuzz_parity:") and " 0 failures" in last, last
     assert int(last.split()[1]) > 200      # it did run a few hundred cases
+
+
+def test_library_comm_single_rank(pkg):
+    """nns_comm_* (the exchange of the one-process-per-GPU form) with ONE rank: unique id, collective
+    create, the library-issued ncclAllReduce(uint64, min) on the caller's stream, RCCL's own rank count.
+    (More ranks need more GPUs: the driver's multi-GPU bench; bench.py cross-checks the library exchange
+    against torch.distributed's all_reduce there.)"""
+    uid = pkg.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = pkg.Comm(uid, 1, 0, 0)
+    assert comm.size() == 1
+    keys = torch.randint(0, 2 ** 62, (65536,), dtype=torch.int64, device="cuda")
+    keys[5] = pkg.NNS_KEY_NONE
+    before = keys.clone()
+    pkg.allreduce_min_keys(keys, comm=comm)
+    torch.cuda.synchronize()
+    assert torch.equal(keys, before)
+    comm.close()
+    with pytest.raises(pkg.NNSError):
+        pkg.Comm(uid[:64], 1, 0, 0)            # a truncated id is rejected, not passed to RCCL
+    with pytest.raises(pkg.NNSError):
+        pkg.Comm(uid, 2, 5, 0)                 # rank out of range
+
+
+def test_in_library_multi_bf16_and_soa(pkg, orc):
+    """nns_search_bf16_multi and NNS_REFS_SOA through nns_search_f32_multi (a shard of a dimension-major
+    array is a column range: strided upload), rehearsed with virtual shards on the one GPU."""
+    rng = np.random.default_rng(56)
+    m, n, k = 300, 40000, 64
+    q = rng.random((m, k), dtype=np.float32)
+    r = rng.random((n, k), dtype=np.float32)
+    r[n - 1] = r[0]
+    q[0] = r[0]
+    want_idx, want_dist = orc.v0_search(q, r, threads=8)
+    rt = np.ascontiguousarray(r.T)
+    for kwargs in ({"num_devices": 0}, {"num_devices": 3, "virtual": True}, {"num_devices": 7, "virtual": True}):
+        idx, dist = pkg.search_multi(q, rt, return_distances=True, refs_soa=True, **kwargs)
+        assert np.array_equal(idx, want_idx), kwargs
+        assert np.array_equal(_bits(dist), _bits(want_dist)), kwargs
+    qb, rb = orc.round_bf16(q), orc.round_bf16(r)
+    wb_idx, wb_dist = orc.v0_search(qb, rb, threads=8)
+    for kwargs in ({"num_devices": 0}, {"num_devices": 4, "virtual": True}):
+        idx, dist = pkg.search_multi(pkg.to_bf16_bits(qb), pkg.to_bf16_bits(rb), return_distances=True, bf16=True, **kwargs)
+        assert np.array_equal(idx, wb_idx), kwargs
+        assert np.array_equal(_bits(dist), _bits(wb_dist)), kwargs
+    pkg.shutdown()                                  # cached communicators (none on one GPU) + pool
+    assert np.array_equal(pkg.search_multi(q, r, num_devices=2, virtual=True), want_idx)   # still usable
+
+
+def test_multi_entry_is_reentrant(pkg, orc):
+    """nns.h: the whole-call entry points are re-entrant — including nns_search_f32_multi, whose RCCL
+    loader used to be guarded by a plain bool.  Several host threads call it at once (virtual shards)."""
+    import threading
+    rng = np.random.default_rng(4243)
+    jobs = []
+    for (m, n, k) in [(300, 9000, 128), (500, 20000, 16), (129, 7000, 3)]:
+        q = rng.random((m, k), dtype=np.float32)
+        r = rng.random((n, k), dtype=np.float32)
+        jobs.append((q, r, orc.v0_search(q, r, threads=4)[0]))
+    errors = []
+
+    def worker(q, r, want):
+        try:
+            for _ in range(6):
+                if not np.array_equal(pkg.search_multi(q, r, num_devices=3, virtual=True), want):
+                    errors.append("mismatch")
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+
+
+def test_refresh_relatches_nonfinite_refs(pkg, orc):
+    """An index built on refs containing a NaN runs the exact kernels; after the caller overwrites the
+    refs with clean data and refreshes, the MFMA path must come back (and the other way round: clean ->
+    NaN must not produce wrong answers while the flag is stale)."""
+    rng = np.random.default_rng(63)
+    m, n, k = 200, 6000, 64
+    q = rng.random((m, k), dtype=np.float32)
+    r_bad = rng.random((n, k), dtype=np.float32)
+    r_bad[17, 3] = np.nan
+    r_good = rng.random((n, k), dtype=np.float32)
+    qd = torch.from_numpy(q).cuda()
+    rd = torch.from_numpy(r_bad).cuda()
+    ix = pkg.Index(rd)
+    with np.errstate(all="ignore"):
+        want_bad = orc.v0_search(q, r_bad, threads=8)[0]
+    assert np.array_equal(ix.search(qd).cpu().numpy(), want_bad)
+    st = ix.stats()
+    assert st["path"] == 1 and st["nonfinite"] == 1, st
+    rd.copy_(torch.from_numpy(r_good))
+    ix.refresh()
+    assert np.array_equal(ix.search(qd).cpu().numpy(), orc.v0_search(q, r_good, threads=8)[0])
+    st = ix.stats()
+    assert st["path"] == 2 and st["nonfinite"] == 0, st
+    rd.copy_(torch.from_numpy(r_bad))               # clean -> NaN: the flag is stale until stats()
+    ix.refresh()
+    assert np.array_equal(ix.search(qd).cpu().numpy(), want_bad)
+    st = ix.stats()
+    assert st["nonfinite"] == 1 and st["ambiguous"] == m, st       # the device-side check sent every query to the scan
+    assert np.array_equal(ix.search(qd).cpu().numpy(), want_bad)
+    assert ix.stats()["path"] == 1                  # re-latched by stats(): straight to the exact kernels now
+    ix.close()
+
+
+@pytest.mark.timeout(600)
+def test_bench_self_launch_rehearsal():
+    """`python bench.py --gpus 2` exactly as the driver starts it (no launcher): bench.py brings up its
+    own two ranks.  On this one-GPU box they share cuda:0 and exchange through gloo
+    (--rehearse-one-gpu); the merged indices must equal the unsharded search."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--workload", "c3s", "--rehearse-one-gpu", "--verify"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["verified_vs_unsharded"] is True
+    assert d["exchange"]["matches_torch_all_reduce"] is True and d["exchange"]["queries_won_sum_over_ranks"] >= d["config"]["m"]
