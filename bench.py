@@ -452,13 +452,13 @@ def main():
             pkg.trim()
         out["also"] = also
 
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:                             # last thing on stdout (RCCL prints a banner at init)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
