@@ -133,7 +133,7 @@ constexpr int kAblate = NNS_FILTER_ABLATE;
 
 constexpr int F_D = 4;                   // ring depth
 constexpr int F_SLOT_COORD = 32768;      // image bytes of one ring slot (32 fragment steps x 1 KiB)
-constexpr int F_SLOT_NORM = 1024;        // room for the slot's norms (64 or 256 floats)
+constexpr int F_SLOT_NORM = 2048;        // room for the slot's norms (up to 512 floats: the 16-deep tile)
 constexpr int F_SLOT_BYTES = F_SLOT_COORD + F_SLOT_NORM;
 constexpr int F_LDS_BYTES = F_D * F_SLOT_BYTES;
 
@@ -158,7 +158,11 @@ template <int SPB, int QB_>
 struct OpF32T {  // fp32 operands: float4 #b = operands of MFMA k-steps 4b .. 4b+3 (8 dims per fragment)
     static constexpr int kSPB = SPB;          // fragment steps per 32-point image block: KT = 8 * SPB
     static constexpr bool kTile16 = false;    // 32x32 MFMA tiles: a lane owns one query per query block
-    static constexpr bool kLag = true;        // SIMD partners half a block out of phase (+1.3 % on C3)
+    // SIMD partners half a block out of phase (+1.3 % on C3); a 2-step block (KT = 16) has no half to lag by
+    static constexpr bool kLag = SPB >= 4;
+    // the lanes' tau constants (c0, x2 per state) stay in registers: an LDS round trip on the slow path
+    // queues behind the whole workgroup's fragment reads (measured: ~900 cycles each under this load)
+    static constexpr bool kTauInRegs = true;
     using Acc = AccSet;
     static constexpr int kQB = QB_;           // 4 * SPB resident operand registers per query block
     static constexpr int kNW = NNS_F_NW_F32;
@@ -176,7 +180,10 @@ struct OpF32T {  // fp32 operands: float4 #b = operands of MFMA k-steps 4b .. 4b
     }
 };
 using OpF32 = OpF32T<16, NNS_F_QB_F32>;      // KT = 128
-using OpF32K32 = OpF32T<4, NNS_F_QB_F32>;    // KT = 32: the mid-range dimensionalities (k = 8 .. 32)
+using OpF32K32 = OpF32T<4, NNS_F_QB_F32>;    // KT = 32: the mid-range dimensionalities (k = 17 .. 32)
+// KT = 16: the reference driver's own 16-D samples (main.cu:38-51) without zero padding to 32: 2 fragment
+// steps per 32-ref block, 16 blocks = 512 refs per ring slot (norms: two dwordx4 DMA pieces)
+using OpF32K16 = OpF32T<2, NNS_F_QB_F32>;
 using OpF32K64 = OpF32T<8, NNS_F_QB_F32>;    // KT = 64: 32 < k <= 64 without padding to 128
 // KT = 256 (128 < k <= 256): the resident operands of ONE query block already take 128 registers,
 // a ring slot holds one 32-ref block (32 KiB), and the ring turns twice as often per MFMA
@@ -204,6 +211,7 @@ struct OpBF16T {
     static constexpr int kSPB = SPB_;         // 16: KT = 256 (8 k-steps per 16-ref tile); 8: KT = 128 (4 k-steps)
     static constexpr bool kTile16 = true;
     static constexpr bool kLag = false;       // lock-step SIMD partners (lagging them: +1..4 % time on C5)
+    static constexpr bool kTauInRegs = false; // 222-234 VGPRs: the four states' constants live in LDS (read on the slow path)
     using Acc = AccSet16;
     static constexpr int kQB = 2;             // 64 queries per wave = 4 query tiles
     static constexpr int kNW = NNS_F_NW_BF16;
@@ -256,6 +264,7 @@ struct OpBF16T32T {
     static constexpr int kSPB = SPB_;         // fragment steps (16 dims each) per 32-ref block
     static constexpr bool kTile16 = false;
     static constexpr bool kLag = true;
+    static constexpr bool kTauInRegs = true;
     using Acc = AccSet;
     static constexpr int kQB = QB_;
     static constexpr int kNW = NNS_F_NW_BF16;
@@ -313,6 +322,7 @@ struct FilterArgs {
     int *counts;            // [splits][m_pad/32][64 lanes]
     int total_slots, slots_per_split, m_pad, kt;
     int bf16;               // tau mode: 0 fp32 operands, 1 bf16 points, 2 fp32 points rounded to bf16 operands
+    int share_thr;          // short streams: a query's lanes adopt the smallest of their thresholds
 #ifdef NNS_DIAG
     unsigned long long *stamps;   // diagnostic (NNS_FILTER_CLOCK): per-workgroup s_memtime / s_memrealtime
 #endif
@@ -327,9 +337,11 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     constexpr int BLK_BYTES = SPB * 1024;
     constexpr int SLOT_REFS = 32 * BPS;
     constexpr int F_PPW = F_SLOT_COORD / 1024 / F_NW;   // 1 KiB DMA pieces per wave per slot
-    static_assert(32 % SPB == 0 && SPB >= 4, "a slot is 32 fragment steps");
-    static_assert(SLOT_REFS == 32 || SLOT_REFS == 64 || SLOT_REFS == 128 || SLOT_REFS == 256,
-                  "norm piece: one dword or one dwordx4 per lane");
+    static_assert(32 % SPB == 0 && SPB >= 2, "a slot is 32 fragment steps");
+    static_assert(SLOT_REFS == 32 || SLOT_REFS == 64 || SLOT_REFS == 128 || SLOT_REFS == 256 || SLOT_REFS == 512,
+                  "norm pieces: one dword per lane, or dwordx4 pieces of 256 norms");
+    constexpr int F_NP = SLOT_REFS <= 256 ? 1 : SLOT_REFS / 256;   // norm DMA pieces per slot
+    static_assert(SLOT_REFS * 4 <= F_SLOT_NORM, "norm room of a ring slot");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -371,10 +383,12 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // the slow path) instead of 3 registers per state; c1 depends on the tile depth alone and is
     // wave-uniform
     float *tcl = reinterpret_cast<float *>(smem + F_LDS_BYTES) + wave * 512 + lane;
+    if constexpr (!OP::kTauInRegs) {
 #pragma unroll
-    for (int st = 0; st < NS; ++st) {
-        tcl[(2 * st) * 64] = tc[st].c0;
-        tcl[(2 * st + 1) * 64] = tc[st].x2;
+        for (int st = 0; st < NS; ++st) {
+            tcl[(2 * st) * 64] = tc[st].c0;
+            tcl[(2 * st + 1) * 64] = tc[st].x2;
+        }
     }
     const float c1u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tc[0].c1)));
 
@@ -390,8 +404,8 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     if (ns > a.slots_per_split) ns = a.slots_per_split;
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
 
-    // DMA piece p (0 .. F_PPW-1: 1 KiB image pieces; F_PPW: the norms) of slot s (relative to
-    // slot0) into ring position s % F_D
+    // DMA piece p (0 .. F_PPW-1: 1 KiB image pieces; F_PPW .. F_PPW+F_NP-1: the norms) of slot s
+    // (relative to slot0) into ring position s % F_D
     auto issue_piece = [&](int s, int p) __attribute__((always_inline)) {
         const size_t gslot = (size_t)(slot0 + s);
         const unsigned dst = lds_base + (s & (F_D - 1)) * F_SLOT_BYTES;
@@ -403,12 +417,13 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             // wave's DMA count per slot identical; a 32-ref slot also copies the next slot's 32)
             dma4(a.rnorm + gslot * SLOT_REFS + lane, dst + F_SLOT_COORD);
         } else {
-            dma16(a.rnorm + gslot * SLOT_REFS + lane * 4, dst + F_SLOT_COORD);
+            const int np = p - F_PPW;             // 256 norms per piece
+            dma16(a.rnorm + gslot * SLOT_REFS + np * 256 + lane * 4, dst + F_SLOT_COORD + np * 1024);
         }
     };
     auto issue = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p <= F_PPW; ++p) issue_piece(s, p);
+        for (int p = 0; p < F_PPW + F_NP; ++p) issue_piece(s, p);
     };
 
     // ---- per-lane record state ---------------------------------------------------------
@@ -418,21 +433,26 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // one query block / query tile) so that both the appends of a wave and K5's per-query reads
     // touch consecutive 8-byte words
     const size_t lblk0 = (size_t)blockIdx.y * (a.m_pad / QPS) + (size_t)qblk0 * (32 / QPS);
-    CandEntry *list[NS];
-    CandEntry *const list0 = a.lists + lblk0 * (kCandCap * 64) + lane;
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
         thr[st] = __builtin_inff();
+#if defined(NNS_DIAG) && defined(NNS_F_THR_NEGINF)   // timing experiment: the fast path alone (results are wrong)
+        thr[st] = -__builtin_inff();
+#endif
         cnt[st] = 0;
-        list[st] = list0 + st * (kCandCap * 64);
     }
-    // (16x16 tiles: one base pointer + compile-time offsets, no per-state pointer registers)
-    auto list_of = [&](auto st_c) __attribute__((always_inline)) -> CandEntry * {
-        constexpr int st = decltype(st_c)::value;
-        if constexpr (T16) return list0 + st * (kCandCap * 64);
-        else return list[st];
-    };
-
+    // The same lists as a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset: the appends of the
+    // slow path then need no 64-bit VALU address arithmetic (global_store saddr + voffset)
+    char *lbase;
+    {
+        const uintptr_t lb = (uintptr_t)(a.lists + lblk0 * (kCandCap * 64));
+        // (readfirstlane returns a signed int: go through unsigned, or a low word with bit 31 set
+        //  sign-extends over the high half)
+        const unsigned lb_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(lb >> 32));
+        const unsigned lb_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)lb);
+        lbase = (char *)(((uintptr_t)lb_hi << 32) | (uintptr_t)lb_lo);
+    }
+    const unsigned loff = lane * (unsigned)sizeof(CandEntry);
     f32x4 nseed0 = {0.0f, 0.0f, 0.0f, 0.0f}, nseed1 = nseed0;   // 16x16 tiles: the two ref tiles' norms
     // accumulators start at |y'_j|^2 of their rows: rows (r&3) + 8(r>>2) + 4h
     auto seed = [&](typename OP::Acc &acc, const char *slot, int blk) __attribute__((always_inline)) {
@@ -474,37 +494,61 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         // x -> x + 1.002 tau(x) is monotone, so the threshold of the running minimum is the minimum
         // of the thresholds: no separate running-minimum register.  (1.002: a hair wider than K5's
         // own tau, so that the lists are supersets of what K5 needs.)
-        const float d = tmin + tcl[(2 * st + 1) * 64];
-        const float tn = tmin + (tcl[(2 * st) * 64] + c1u * (d > 0.0f ? d : 0.0f)) * 1.002f;
+        float c0v, x2v;
+        if constexpr (OP::kTauInRegs) {
+            c0v = tc[st].c0;
+            x2v = tc[st].x2;
+        } else {
+            c0v = tcl[(2 * st) * 64];
+            x2v = tcl[(2 * st + 1) * 64];
+        }
+        const float d = tmin + x2v;
+        const float tn = tmin + (c0v + c1u * (d > 0.0f ? d : 0.0f)) * 1.002f;
         float t = tn < thr[st] ? tn : thr[st];
-#ifdef NNS_F_SHARE_THR
-        // (Off by default.)  A query lives on 2 (32x32 tiles: lanes l, l ^ 32) or 4 (16x16: l ^ 16,
-        // l ^ 32) lanes, each seeing a different part of every ref block.  Any of their thresholds
-        // is valid for all of them (each is >= final minimum + tau), so they could adopt the
-        // smallest: a lane then stops taking the slow path for refs that a sibling lane has already
-        // beaten.  Measured: short streams (128 slots per workgroup) +1.7 %, C3 -0.17 %, C5 -0.2 %:
-        // the headline shapes win, the flag stays for builds that serve mid-size problems.
-        // (Wave-uniform slow path: every lane is active here.)
-        t = fminf(t, __shfl_xor(t, 32, 64));
-        if constexpr (T16) t = fminf(t, __shfl_xor(t, 16, 64));
-#endif
-        thr[st] = t;
+        // A query lives on 2 (32x32 tiles: lanes l, l ^ 32) or 4 (16x16: l ^ 16, l ^ 32) lanes, each seeing
+        // a different part of every ref block.  Any of their thresholds is valid for all of them (each
+        // is >= final minimum + tau), so they may adopt the smallest: a lane then stops taking the slow
+        // path for refs a sibling lane has already beaten.  Pays on SHORT ref streams (where nearly
+        // every tile is slow), costs 0.2 % on C3 / C5: a launch-time choice by stream length
+        // (launch_filter).  Row swaps (v_permlane32_swap / 16_swap, gfx950), not ds_bpermute: no LDS
+        // round trip.  (Wave-uniform slow path: every lane is active here.)
+        if (a.share_thr) {
+            const unsigned tb = __float_as_uint(t);
+            const auto s32 = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);
+            t = fminf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));          // min(t[l], t[l ^ 32])
+            if constexpr (T16) {
+                const unsigned tb2 = __float_as_uint(t);
+                const auto s16 = __builtin_amdgcn_permlane16_swap(tb2, tb2, false, false);
+                t = fminf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));      // min(t[l], t[l ^ 16])
+            }
+        }
+        // (a finite threshold: "x <= thr" then also excludes the +INF scores of padding refs)
+        thr[st] = fminf(t, 3.4028234663852886e38f);
     };
-    // Slow path, step 2: one finished score x of ref j: append to the state's candidate ring
-    auto record = [&](auto st_c, float x, int j) __attribute__((always_inline)) {
+    // Slow path, step 2: one finished score x of ref j: append to the state's candidate ring (thr is finite
+    // here — tighten clamps it — so "x <= thr" also excludes the +INF scores of padding refs).  `roomy`
+    // (wave-uniform, computed once per slow tile): no lane of the wave is within a tile's worth of entries of
+    // its ring's capacity, so the ring-wrap check — a load, hence a vmcnt wait that also drains the DMA ring —
+    // is skipped by a scalar branch; it only runs on monotone inputs (every ref a new record).
+    auto record = [&](auto st_c, float x, int j, bool roomy) __attribute__((always_inline)) {
         constexpr int st = decltype(st_c)::value;
-        if (x <= thr[st] && x < __builtin_inff()) {
-            const int pos = cnt[st] & (kCandCap - 1);
-            CandEntry *const lst = list_of(st_c);
-            if ((cnt[st] & kCandCountMask) >= kCandCap) {
-                // ring wrap: the slot's old entry may only be dropped if it is above the
-                // current threshold (then it can never be within tau of the final minimum)
-                if (lst[pos * 64].s <= thr[st]) cnt[st] |= kCandOverflow;
+        if (x <= thr[st]) {
+            const unsigned off = loff + (unsigned)(st * (kCandCap * 64 * (int)sizeof(CandEntry))) +
+                                 (unsigned)(cnt[st] & (kCandCap - 1)) * (unsigned)(64 * sizeof(CandEntry));
+            CandEntry *const dst = reinterpret_cast<CandEntry *>(lbase + off);
+            if (__builtin_expect(!roomy, 0)) {
+                // ring wrap: the slot's old entry may only be dropped if it is above the current
+                // threshold (then it can never be within tau of the final minimum)
+                if ((cnt[st] & kCandCountMask) >= kCandCap && dst->s <= thr[st]) cnt[st] |= kCandOverflow;
             }
             CandEntry e;
             e.s = x;
             e.j = j;
-            lst[pos * 64] = e;
+#if defined(NNS_DIAG) && defined(NNS_F_NOSTORE)   // timing experiment: the slow path without its global store
+            asm volatile("" ::"v"(e.s), "v"(e.j), "v"(dst));
+#else
+            *dst = e;
+#endif
             ++cnt[st];
         }
     };
@@ -528,25 +572,46 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         }
     };
     // slow path of one state: every score of the block against the lane's threshold
+#ifdef NNS_DIAG
+    unsigned diag_slow = 0, diag_tiles = 0;   // slow-path executions / retired (tile, state) pairs of this wave
+    unsigned long long diag_cyc = 0;   // s_memtime ticks spent inside record_all
+#endif
     auto record_all = [&](const typename OP::Acc &acc, int blk_global, auto st_c) __attribute__((always_inline)) {
         constexpr int st = decltype(st_c)::value;
-        // (the tile minimum is recomputed here, on the cold path, rather than kept live across the
-        //  branch: the 128-deep fp32 kernel has no register to spare)
+#ifdef NNS_DIAG
+        ++diag_slow;
+        const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
+#endif
+        // (the tile minimum is recomputed here, on the cold path, rather than kept live across the branch)
         tighten(st_c, tile_min(acc, st_c));
+        // is any lane of the wave about to wrap its 64-entry ring (monotone inputs)?
+        const bool roomy = __builtin_amdgcn_ballot_w64((cnt[st] & kCandCountMask) + 16 > kCandCap) == 0ull;
         if constexpr (T16) {
             const f32x4 &lo = acc.template at<0, st>();
             const f32x4 &hi = acc.template at<1, st>();
             const int jbase = blk_global * 32 + 4 * (lane >> 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) record(st_c, lo[r], jbase + r);
+            for (int r = 0; r < 4; ++r) record(st_c, lo[r], jbase + r, roomy);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) record(st_c, hi[r], jbase + 16 + r);
+            for (int r = 0; r < 4; ++r) record(st_c, hi[r], jbase + 16 + r, roomy);
         } else {
+            // Typically ONE lane has ONE score to append, and every instruction of this path delays the whole
+            // workgroup at the next slot barrier: test the scores four at a time first (wave-uniform), descend
+            // only into a group that has one.
             const f32x16 &t = acc.template at<st>();
             const int jbase = blk_global * 32 + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) record(st_c, t[r], jbase + (r & 3) + 8 * (r >> 2));
+            for (int g = 0; g < 4; ++g) {
+                const float gm = fminf(fminf(t[4 * g], t[4 * g + 1]), fminf(t[4 * g + 2], t[4 * g + 3]));
+                if (__builtin_amdgcn_ballot_w64(gm <= thr[st]) != 0ull) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) record(st_c, t[4 * g + e], jbase + e + 8 * g, roomy);   // rows (r & 3) + 8 (r >> 2)
+                }
+            }
         }
+#ifdef NNS_DIAG
+        diag_cyc += __builtin_amdgcn_s_memtime() - diag_t0;
+#endif
     };
     // record collection at the end of a ref block
     auto epilogue = [&](const typename OP::Acc &acc, int blk_global) __attribute__((always_inline)) {
@@ -569,6 +634,9 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
                 constexpr int st = decltype(st_c)::value;
                 const float tm = tile_min(acc, st_c);
+#ifdef NNS_DIAG
+                ++diag_tiles;
+#endif
 #ifdef NNS_F_NOEXPECT
                 if (__builtin_amdgcn_ballot_w64(tm <= thr[st]) != 0ull)   // rare: ~ln(n) tiles per lane
 #else
@@ -605,8 +673,9 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                     if (hm[st] != 0ull) {
                         const f32x4 &o = acc.template at<ot, st>();
                         tighten(st_c, tmh[st]);
+                        const bool roomy = __builtin_amdgcn_ballot_w64((cnt[st] & kCandCountMask) + 4 > kCandCap) == 0ull;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) record(st_c, o[r], jbase + r);
+                        for (int r = 0; r < 4; ++r) record(st_c, o[r], jbase + r, roomy);
                     }
                 });
             }
@@ -657,7 +726,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     constexpr int PF = OP::kPrefetch;
     constexpr int RING = PF < 4 ? 4 : 8;
     constexpr int LAGOFF = SPB / 2;
-    static_assert(PF < RING && 32 % RING == 0 && PF <= LAGOFF, "prefetch ring");
+    static_assert(PF < RING && 32 % RING == 0 && (!OP::kLag || PF <= LAGOFF), "prefetch ring");
     typename OP::Acc acc;
     if constexpr (T16) {
         const f32x4 inf4 = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
@@ -707,13 +776,13 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
 #ifdef NNS_F_DMA_SP
                 constexpr int sp = NNS_F_DMA_SP;
 #else
-                constexpr int sp = (F_PPW + 1) * 2 <= 14 ? 2 : 1;   // steps between pieces
+                constexpr int sp = (F_PPW + F_NP) * 2 <= 14 ? 2 : 1;   // steps between pieces
 #endif
-                static_assert(d0 + sp * (F_PPW + 1) <= 32, "DMA pieces must fit the interval");
+                static_assert(d0 + sp * (F_PPW + F_NP) <= 32, "DMA pieces must fit the interval");
 #ifdef NNS_F_DMA_BURST
                 if constexpr (t == d0) issue(s + 2);
 #else
-                if constexpr (t >= d0 && t < d0 + sp * (F_PPW + 1) && (t - d0) % sp == 0)
+                if constexpr (t >= d0 && t < d0 + sp * (F_PPW + F_NP) && (t - d0) % sp == 0)
                     issue_piece(s + 2, (t - d0) / sp);
 #endif
             }
@@ -757,38 +826,51 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // prologue: slots 0 and 1 in flight; confirm slot 0; start interval 0's first fragments
     issue(0);
     issue(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(F_PPW + 1) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(F_PPW + F_NP) : "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (T16) seed16(ring(0), 0, I0c{});   // the first block's tile-0 norms
     // (LAG 1 reads ring slot -1 here: garbage in, discarded — see the interval)
     static_for<PF>([&](auto t) __attribute__((always_inline)) {
         constexpr int tt = decltype(t)::value;
-        if (lag) fr[tt % RING] = *frag_ptr(ring(-1), BPS - 1, SPB - LAGOFF + tt);
-        else fr[tt % RING] = *frag_ptr(ring(0), 0, tt);
-    });
-    for (int s = 0; s < ns; ++s) {
-        if constexpr ((kAblate & 1) == 0) {
-            // my share of slot s+1 has landed (issued an interval ago; the only DMA in flight)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // everyone's share of slot s+1 has landed; everyone is done with slot s-2
-            __builtin_amdgcn_s_barrier();
-        }
         if constexpr (OP::kLag) {
-            if (!half) interval(I0{}, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
-            else if (lag) interval(I1{}, I1{}, s, ring(s), ring(s - 1), ring(s + 1));
-            else interval(I0{}, I1{}, s, ring(s), ring(s - 1), ring(s + 1));
+            if (lag) fr[tt % RING] = *frag_ptr(ring(-1), BPS - 1, SPB - LAGOFF + tt);
+            else fr[tt % RING] = *frag_ptr(ring(0), 0, tt);
         } else {
-            // lock-step partners, one code path (staggering only their DMA issue steps, or packing /
-            // spreading the pieces differently, measured +-0.5 % on C5)
-            interval(I0{}, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
-            // The interval ends on the MFMAs that finish ref tile 1, which is retired in the NEXT
-            // interval: hipcc is free to split / copy those accumulators at the loop back-edge
-            // (it did: v_mov of single elements right behind the MFMAs = stale reads).  Whatever it
-            // does with them now happens behind the 8 wait states their readers need.
-#ifndef NNS_F_NOLATCHFENCE   // (timing experiments only: without it the results are wrong)
-            if constexpr (T16) OP::mma16_tail_fence(acc);
-#endif
+            fr[tt % RING] = *frag_ptr(ring(0), tt / SPB, tt % SPB);
         }
+    });
+    // The slot loop, one copy per interval variant (the dispatch is wave-uniform and loop-invariant): with
+    // the three variants as branches inside ONE loop, hipcc parks the accumulators in different register
+    // tuples at the merge and at the loop header and reconciles them with ~48 v_mov at every back-edge.
+    // Every wave executes exactly ns barriers whichever copy it runs.
+    auto slot_loop = [&](auto lag_c, auto dph_c) __attribute__((always_inline)) {
+        for (int s = 0; s < ns; ++s) {
+            if constexpr ((kAblate & 1) == 0) {
+                // my share of slot s+1 has landed (issued an interval ago; the only DMA in flight)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // everyone's share of slot s+1 has landed; everyone is done with slot s-2
+                __builtin_amdgcn_s_barrier();
+            }
+            interval(lag_c, dph_c, s, ring(s), ring(s - 1), ring(s + 1));
+            if constexpr (!OP::kLag) {
+                // lock-step partners (staggering only their DMA issue steps, or packing / spreading the
+                // pieces differently, measured +-0.5 % on C5).  The interval ends on the MFMAs that finish
+                // ref tile 1, which is retired in the NEXT interval: hipcc is free to split / copy those
+                // accumulators at the loop back-edge (it did: v_mov of single elements right behind the
+                // MFMAs = stale reads).  Whatever it does with them now happens behind the 8 wait states
+                // their readers need.
+#ifndef NNS_F_NOLATCHFENCE   // (timing experiments only: without it the results are wrong)
+                if constexpr (T16) OP::mma16_tail_fence(acc);
+#endif
+            }
+        }
+    };
+    if constexpr (OP::kLag) {
+        if (!half) slot_loop(I0{}, I0{});
+        else if (lag) slot_loop(I1{}, I1{});
+        else slot_loop(I0{}, I1{});
+    } else {
+        slot_loop(I0{}, I0{});
     }
     if constexpr (T16) {   // ref tile 1 of the last block is still to be retired
         OP::mma16_tail_fence(acc);
@@ -813,6 +895,12 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
 #pragma unroll
     for (int st = 0; st < NS; ++st) a.counts[(lblk0 + st) * 64 + lane] = cnt[st];
 #ifdef NNS_DIAG
+    if (a.stamps && lane == 0) {   // totals behind the per-workgroup stamps
+        unsigned long long *tot = a.stamps + 4 * (size_t)gridDim.x * gridDim.y;
+        atomicAdd(tot, (unsigned long long)diag_slow);
+        atomicAdd(tot + 1, (unsigned long long)diag_tiles);
+        atomicAdd(tot + 2, diag_cyc);
+    }
     if (a.stamps && threadIdx.x == 0) {
         unsigned long long *o = a.stamps + 4 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
         o[0] = st_t0;
@@ -887,6 +975,9 @@ int launch_mfma_selftest(int kt, int bf16, const float *a, const float *b, const
 }
 
 // ---- planning + launch ---------------------------------------------------------------
+// streams of at most this many 32-ref tiles per workgroup run with shared lane thresholds
+constexpr int64_t kShareThrMaxTiles = 2048;
+
 int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
 {
     if (mixed) bf16 = true;   // fp32 points, bf16 operands: the bf16 filter's geometry
@@ -896,7 +987,8 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
         else if (k <= 256) kt = 256;
         else if (k <= 512) kt = 512;   // OpBF16K512
     } else {
-        if (k <= 32) kt = 32;          // OpF32K32: 4 fragment steps per block, 8 blocks per slot
+        if (k <= 16) kt = 16;          // OpF32K16: 2 fragment steps per block, 16 blocks per slot
+        else if (k <= 32) kt = 32;     // OpF32K32: 4 fragment steps per block, 8 blocks per slot
         else if (k <= 64) kt = 64;     // OpF32K64: 8 steps per block, 4 blocks per slot
         else if (k <= 128) kt = 128;
         else if (k <= 256) kt = 256;   // OpF32K256: 32 fragment steps per block, 1 block per slot
@@ -944,6 +1036,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
     if (splits > 65535) splits = 65535;
     g->slots_per_split = divup(g->total_slots, splits);
     g->splits = divup(g->total_slots, g->slots_per_split);
+    g->slot_pts = slot_pts;
     return NNS_OK;
 }
 
@@ -983,22 +1076,32 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
     a.m_pad = g.m_pad;
     a.kt = g.kt;
     a.bf16 = g.mixed ? 2 : g.bf16;
+    // short streams (every tile of a stream of T tiles is slow until ~128 tiles in): share thresholds
+    // among a query's lanes; long streams (C3: 16384 tiles, C5: 8192) keep them private
+    a.share_thr = (int64_t)g.slots_per_split * (g.n_pad / g.total_slots / 32) <= kShareThrMaxTiles ? 1 : 0;
+#ifdef NNS_F_NOSHARE   // (A/B builds)
+    a.share_thr = 0;
+#endif
 #ifdef NNS_DIAG
     a.stamps = nullptr;
     const char *clk = getenv("NNS_FILTER_CLOCK");
     const size_t nwg = (size_t)g.qgroups * g.splits;
-    if (clk && atoi(clk)) NNS_HIP(hipMalloc(&a.stamps, nwg * 4 * sizeof(unsigned long long)));
+    if (clk && atoi(clk)) {
+        NNS_HIP(hipMalloc(&a.stamps, (nwg * 4 + 8) * sizeof(unsigned long long)));
+        NNS_HIP(hipMemsetAsync(a.stamps, 0, (nwg * 4 + 8) * sizeof(unsigned long long), st));
+    }
 #endif
     const int rc = g.bf16 ? (g.kt == 128   ? launch_filter_t<OpBF16K128>(g, a, st)
                              : g.kt == 512 ? launch_filter_t<OpBF16K512>(g, a, st)
                                            : launch_filter_t<OpBF16Active>(g, a, st))
-                          : (g.kt == 32    ? launch_filter_t<OpF32K32>(g, a, st)
+                          : (g.kt == 16    ? launch_filter_t<OpF32K16>(g, a, st)
+                             : g.kt == 32  ? launch_filter_t<OpF32K32>(g, a, st)
                              : g.kt == 64  ? launch_filter_t<OpF32K64>(g, a, st)
                              : g.kt == 256 ? launch_filter_t<OpF32K256>(g, a, st)
                                            : launch_filter_t<OpF32>(g, a, st));
 #ifdef NNS_DIAG
     if (a.stamps) {   // diagnostic: synchronous read-out, median clock over workgroups
-        std::vector<unsigned long long> h(nwg * 4);
+        std::vector<unsigned long long> h(nwg * 4 + 8);
         NNS_HIP(hipStreamSynchronize(st));
         NNS_HIP(hipMemcpy(h.data(), a.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         std::vector<double> ghz, us;
@@ -1017,6 +1120,8 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
                             "workgroup main loop %.1f us median (%.1f .. %.1f), first start to last end %.1f us\n",
                     ghz[ghz.size() / 2], ghz.front(), ghz.back(), ghz.size(), us[us.size() / 2], us.front(), us.back(),
                     (double)(last - first) * 0.01);
+        fprintf(stderr, "[nns] filter slow path: %llu of %llu (tile, state) retirements (fp32 tiles only), %.0f memtime ticks each, share=%d\n",
+                h[nwg * 4], h[nwg * 4 + 1], h[nwg * 4] ? (double)h[nwg * 4 + 2] / (double)h[nwg * 4] : 0.0, a.share_thr);
         (void)hipFree(a.stamps);
     }
 #endif

@@ -29,13 +29,12 @@ void set_error(const char *fmt, ...)
 
 using namespace nns;
 
-// one point of a tile image: 512 bytes (128 fp32 dims or 256 bf16 dims; the 32-deep fp32 tile is
-// allocated at the same size), 1 KiB for the 256-deep fp32 tile
-static size_t img_row_bytes(const FilterGeom &g)
-{
-    const size_t b = (size_t)g.kt * (g.bf16 ? 2 : 4);
-    return b > 512 ? b : 512;
-}
+// one point of a tile image
+static size_t img_row_bytes(const FilterGeom &g) { return (size_t)g.kt * (g.bf16 ? 2 : 4); }
+// The filter's ring DMA runs two slots (32 KiB of image, slot_pts norms each) past the last one without a
+// bounds branch: images and norm arrays carry that much padding (+ the over-read of a 128-norm piece)
+static size_t img_bytes(const FilterGeom &g, int pts_pad) { return (size_t)pts_pad * img_row_bytes(g) + 2 * 32768 + 4096; }
+static size_t norm_bytes(const FilterGeom &g, int pts_pad) { return ((size_t)pts_pad + 2 * g.slot_pts + 256) * sizeof(float); }
 // below this many queries the AUTO path skips the MFMA filter (and, in the whole-call
 // entry points, its ref pre-pass too)
 static const int kTinyM = 64;
@@ -264,9 +263,8 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
             const FilterGeom &g = ix->geom;
             size_t ws = 0;
             prep_workspace_bytes(g.kt, &ws);
-            // + 512 rows: the filter's ring DMA runs two slots (64 or 256 refs each) past the last one
-            if (pool_alloc(&ix->rimg, (size_t)(g.n_pad + 512) * img_row_bytes(g)) != hipSuccess ||
-                pool_alloc(&ix->rnorm, (size_t)(g.n_pad + 512) * sizeof(float)) != hipSuccess ||
+            if (pool_alloc(&ix->rimg, img_bytes(g, g.n_pad)) != hipSuccess ||
+                pool_alloc(&ix->rnorm, norm_bytes(g, g.n_pad)) != hipSuccess ||
                 pool_alloc(&ix->mean, (size_t)g.kt * sizeof(float)) != hipSuccess ||
                 pool_alloc(&ix->mean_ws, ws) != hipSuccess ||
                 pool_alloc(&ix->scal, sizeof(DevScalars)) != hipSuccess) {
@@ -350,7 +348,7 @@ static int ensure_query_ws(nns_index *ix, int m)
         ix->amb_list = nullptr;
         ix->multi_list = nullptr;
         ix->m_cap = 0;
-        if (pool_alloc(&ix->qimg, (size_t)gq.m_pad * img_row_bytes(gq)) != hipSuccess ||
+        if (pool_alloc(&ix->qimg, img_bytes(gq, gq.m_pad)) != hipSuccess ||
             pool_alloc(&ix->qnorm, (size_t)gq.m_pad * sizeof(float)) != hipSuccess ||
             pool_alloc(&ix->amb_list, (size_t)gq.m_pad * sizeof(int)) != hipSuccess ||
             pool_alloc(&ix->multi_list, (size_t)gq.m_pad * sizeof(int)) != hipSuccess) {
@@ -737,9 +735,9 @@ int nns_search_bf16_ex(int k, int m, int n, const uint16_t *s_points, const uint
 int nns_warmup(int device)
 {
     NNS_TRY(ensure_device_ok(device));
-    // (k, m, n, bf16): K1a, K1b, the fp32 tile depths 32 / 64 / 128 / 256, the bf16-operand tile for fp32
+    // (k, m, n, bf16): K1a, K1b, the fp32 tile depths 16 / 32 / 64 / 128 / 256, the bf16-operand tile for fp32
     // points (512), the bf16 tiles 128 / 256 / 512
-    static const int shapes[][4] = {{3, 64, 512, 0},   {16, 1, 512, 0},   {16, 64, 512, 0},  {40, 64, 512, 0},
+    static const int shapes[][4] = {{3, 64, 512, 0},   {16, 1, 512, 0},   {16, 64, 512, 0},  {24, 64, 512, 0}, {40, 64, 512, 0},
                                     {100, 64, 512, 0}, {200, 64, 512, 0}, {300, 64, 512, 0}, {64, 64, 512, 1},
                                     {200, 64, 512, 1}, {300, 64, 512, 1}};
     const int kmax = 300, mmax = 64, nmax = 512;

@@ -88,6 +88,7 @@ struct FilterGeom {
     int splits;           // grid.y: contiguous ref ranges
     int slots_per_split;
     int qgroups;          // grid.x
+    int slot_pts;         // refs per ring slot
 };
 
 // One candidate of the filter: score s = |y'|^2 - 2 x'.y' and shard-local ref index.
@@ -153,6 +154,16 @@ __host__ __device__ inline float tau_of(const TauConsts &t, float a)
 {
     const float d = a + t.x2;
     return t.c0 + t.c1 * (d > 0.0f ? d : 0.0f);
+}
+
+// The record threshold a filter lane derives from a score a it has seen: a + 1.002 tau(a) (a hair
+// wider than K5's own tau so that the lists are supersets of what K5 needs).  Monotone in a, so the
+// threshold of a minimum is the minimum of the thresholds.  (The filter's slow path, tighten, spells the
+// same expression with its constants in registers.)
+__host__ __device__ inline float record_threshold(const TauConsts &t, float a)
+{
+    const float d = a + t.x2;
+    return a + (t.c0 + t.c1 * (d > 0.0f ? d : 0.0f)) * 1.002f;
 }
 
 // device-side scalars shared between kernels of one index

@@ -366,6 +366,10 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, c
         return NNS_OK;
     }
     switch (kt) {
+    case 16:
+        hipLaunchKernelGGL(image_kernel<16>, dim3(blocks), dim3(256), 0, st, k, npts, pts, mean,
+                           scale, pad_norm, img, norms, max_norm_bits, maxabs_bits);
+        break;
     case 32:
         hipLaunchKernelGGL(image_kernel<32>, dim3(blocks), dim3(256), 0, st, k, npts, pts, mean,
                            scale, pad_norm, img, norms, max_norm_bits, maxabs_bits);

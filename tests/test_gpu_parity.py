@@ -558,10 +558,10 @@ def test_awkward_query_counts_balance(pkg, orc):
 
 
 @pytest.mark.parametrize("shape", [(1000, 5000, 16), (300, 70001, 8), (2049, 777, 31), (65, 300000, 32),
-                                   (700, 20001, 12), (4096, 4096, 20)])
+                                   (700, 20001, 12), (4096, 4096, 20), (1024, 300001, 16), (130, 1100000, 9)])
 def test_filter_k32_tile_shapes(pkg, orc, shape):
-    """8 <= k <= 32 runs the 32-deep fp32 MFMA tile (8 image blocks per ring slot): ragged m / n / k
-    vs the oracle, forced and under AUTO, whole and sharded."""
+    """8 <= k <= 16 runs the 16-deep fp32 MFMA tile (16 image blocks = 512 refs per ring slot), 16 < k <= 32
+    the 32-deep one (8 blocks): ragged m / n / k vs the oracle, forced and under AUTO, whole and sharded."""
     m, n, k = shape
     rng = np.random.default_rng(500 + k)
     q = rng.random((m, k), dtype=np.float32)
@@ -570,7 +570,7 @@ def test_filter_k32_tile_shapes(pkg, orc, shape):
     ix = pkg.Index(torch.from_numpy(r).cuda())
     ix.search(torch.from_numpy(q).cuda())
     st = ix.stats()
-    assert st["path"] == 2 and st["k_tile"] == 32, st
+    assert st["path"] == 2 and st["k_tile"] == (16 if k <= 16 else 32), st
     ix.close()
 
 

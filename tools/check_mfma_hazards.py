@@ -13,8 +13,11 @@ generated code after every build:
   that reads them as A/B operand or as a DIFFERENT (partially overlapping) C tuple.
   (An MFMA accumulating in place on exactly the same tuple is the supported back-to-back form.)
 
-WAIT = 8 for the 4-pass 16x16x32 (what hipcc itself inserts behind the builtin: s_nop 7), 12 for
-the 32x32x16 / 32x32x2 forms (s_nop 11).  s_nop N counts N + 1 wait states, every other
+WAIT = 8 for the 4-pass 16x16x32 (what hipcc itself inserts behind the builtin: s_nop 7) — the
+only MFMA the kernels issue from inline asm.  The 32x32x16 / 32x32x2 forms go through the
+compiler builtins: hipcc's own hazard recognizer places their wait states (e.g. exactly 11 in
+front of a VALU overwrite of an 8-pass result) and they are not re-checked here.
+s_nop N counts N + 1 wait states, every other
 instruction 1 (a lower bound on the time it takes).  The fall-through path is scanned from the
 top of each kernel; every branch taken while results are pending (conditional, or the loop's
 back-edge) is followed into its target for as long as they stay pending.
@@ -31,8 +34,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nns-cuda_amd", "csrc")
 
-WAITS = {"v_mfma_f32_16x16x32_bf16": 8, "v_mfma_f32_32x32x16_bf16": 12, "v_mfma_f32_32x32x2_f32": 12,
-         "v_mfma_f32_16x16x4_f32": 8}
+WAITS = {"v_mfma_f32_16x16x32_bf16": 8}   # the inline-asm MFMA; builtin forms are the compiler's business
 
 
 def compile_isa() -> str:
@@ -130,8 +132,8 @@ def check_kernel(name: str, lines) -> list:
             for p in pending:
                 p[1] -= 1
             pending = [p for p in pending if p[1] > 0]
-            if is_mfma:
-                pending.append([vregs(ops[0]), WAITS.get(mn, 12), mn, ln, ops[0]])
+            if is_mfma and mn in WAITS:   # (builtin MFMA forms: hipcc's hazard recognizer owns their wait states)
+                pending.append([vregs(ops[0]), WAITS[mn], mn, ln, ops[0]])
             if not follow and not pending:
                 break
         return side
