@@ -26,7 +26,8 @@ A step = one pass of the hot path over the batch, inputs already resident in HBM
   K2 query pre-pass, K3 fp32 MFMA filter, K5 finalize (prove or re-rank), exact
   re-rank of ambiguous queries                         -> nns_index_search
   [N > 1] all-reduce(min) of the keys over RCCL
-  unpack keys -> int32 indices                         -> nns_keys_unpack
+  unpack keys -> int32 indices                         -> nns_keys_unpack (N = 1: nns_index_search_indices
+                                                          does search + unpack; the 3-D exact kernel in one launch)
 (the reference times alloc + H2D + D2H too, main.cu:73-75; the PCIe-inclusive figure of the
 whole-call drop-in is reported in DESIGN.md, never here).
 
@@ -196,11 +197,14 @@ def run_workload(ctx, name, steps, warmup, seed=1000):
     mixed = name == "c3x"
     ix = pkg.Index(r, index_base=beg, path="auto", profile=True, filter_bf16=mixed)
 
+    idx_buf = torch.empty(m, dtype=torch.int32, device=dev)
+
     def step():
         ix.refresh()                          # K2 on refs
+        if dist is None:                      # one shard: keys + unpacked indices from the search itself
+            return ix.search_indices(q, keys, idx_buf)
         ix.search_keys(q, keys)               # K2 queries, K3 filter, K5, re-rank
-        if dist is not None:
-            pkg.allreduce_min_keys(keys, comm=ctx.comm)   # MINLOC-style exchange: one min all-reduce
+        pkg.allreduce_min_keys(keys, comm=ctx.comm)   # MINLOC-style exchange: one min all-reduce
         return pkg.keys_unpack(keys)
 
     for _ in range(warmup):

@@ -187,6 +187,14 @@ int nns_search_bf16_ex(int k, int m, int n, const uint16_t *s_points,
                        const uint16_t *r_points, int *idx_out, float *dist_out,
                        int num_shards, unsigned flags, int device);
 
+/* nns_index_search + nns_keys_unpack in one call for the single-shard case (what the reference's
+ * cudaCall hands back is indices): keys_dev[m] as above AND idx_dev[m] = index of each key (0 for
+ * NNS_KEY_NONE, as V0), dist_dev (optional) = its fp32 distance.  The low-dimensional exact kernel
+ * writes all three in its one launch; the other paths append the unpack kernel.  q_dev has the
+ * index's dtype (fp32, or bf16 bit patterns). */
+int nns_index_search_indices(nns_index *ix, int m, const void *q_dev, nns_key *keys_dev,
+                             int *idx_dev, float *dist_dev, void *stream);
+
 int nns_index_stats(nns_index *ix, nns_stats *out);
 
 /* The queries of the LAST nns_index_search on the MFMA path whose answer was NOT settled by the

@@ -120,11 +120,29 @@ __device__ __forceinline__ nns_key wave_min_key(nns_key v)
 // ---------------------------------------------------------------------------
 // K1a: lane = query, wave-uniform refs
 // ---------------------------------------------------------------------------
-// K1a geometry: a workgroup stages its ref range in LDS once (coalesced), then every lane
-// walks it in chunks of CH refs read by BROADCAST ds_read_b128 (all lanes, same address:
-// one LDS access, no bank conflict) against QPL queries held in registers.  (Reading the
-// wave-uniform refs through the scalar cache instead thrashes it: 8 co-resident
-// workgroups stream 8 different ref ranges through 16 KiB.)
+// K1a geometry: a lane holds QPL queries in registers; a workgroup of NW waves (all NW waves hold the SAME
+// 64 x QPL queries) stages a tile of its ref range in LDS (coalesced) and its waves walk the tile's chunks
+// of CH refs round-robin, each chunk read by BROADCAST ds_read_b128 (all lanes, same address: one LDS
+// access, no bank conflict).  (Reading the wave-uniform refs through the scalar cache instead thrashes
+// it: the co-resident workgroups stream different ref ranges through 16 KiB.)
+//
+// The inner loop is branch-free: per pair the 3K - 1 V0 operations (the first add of the chain is
+// 0 + x = x, exact), per chunk a min tree and TWO conditional moves — the lane's best distance and the
+// first ref of the CHUNK it came from.  Keys travelling through the merges carry (distance, chunk start):
+// integer order is still (distance, then lowest index) because chunks are disjoint ascending ranges;
+// the exact index inside the winning chunk is recovered once per QUERY by whoever writes the final key
+// (write_final).  (Recovering it inside the loop behind a wave-uniform "any lane improved" branch was
+// taken by almost every chunk of a short ref range — a lane improves on its c-th chunk with probability
+// ~1/c and a wave has 64 x QPL of them — and cost 25 % more VALU instructions: PMC, 12.2 per pair vs 9.)
+//
+// Merges, all inside the one launch (V7 does its second stage on the host, core.cu:675-696):
+//   * the NW waves of a workgroup: packed keys through LDS;
+//   * the ref splits of a query tile (grid.y; the V7 idea, core.cu:662): a returning 64-bit atomicMin per
+//     query into an accumulator the index owns (memory-side atomics: the 8 XCDs' L2s are not coherent
+//     with each other inside a kernel, and a release / acquire fence pair per workgroup — L2 write-back +
+//     invalidate — cost 3x the kernel, measured), then one arrival counter per query tile; the LAST
+//     workgroup to arrive reads the accumulator back, recovers the exact indices, writes the final keys
+//     (and, optionally, the unpacked indices / distances) and re-arms accumulator and counter.
 #ifndef NNS_K1A_QPL
 #define NNS_K1A_QPL 2
 #endif
@@ -133,22 +151,74 @@ constexpr int K1A_LDS_FLOATS = 4096;   // 16 KiB ref tile
 #ifndef NNS_K1A_WAVES
 #define NNS_K1A_WAVES 8192   // target number of waves in the grid (8 per SIMD)
 #endif
+#ifndef NNS_K1A_MAXNW
+#define NNS_K1A_MAXNW 16     // waves per workgroup, at most
+#endif
+constexpr int K1A_MAXNW = NNS_K1A_MAXNW;
 
 template <int K>
 struct K1aChunk {
     static constexpr int value = K <= 4 ? 8 : (K <= 8 ? 4 : 2);   // CH * K floats, multiple of 8
 };
 
+// the cross-split stage of K1a (device pointers into the index's exact workspace)
+struct K1aMerge {
+    nns_key *acc;       // [m] accumulator, NNS_KEY_NONE between launches
+    int *cnt;           // [qtiles] arrivals per query tile, zero between launches
+    int splits;
+    int *idx_out;       // optional fused unpack of the final keys
+    float *dist_out;
+};
+
 template <int K>
-__global__ __launch_bounds__(256) void exact_lane_query_kernel(
+__device__ __forceinline__ void write_final(const K1aMerge &mg, nns_key *keys, int qi, nns_key key,
+                                            const float (&qrow)[K], const float *__restrict__ r, int n,
+                                            int64_t index_base)
+{
+    constexpr int CH = K1aChunk<K>::value;
+    if (key != (nns_key)NNS_KEY_NONE) {
+        // recompute the winning chunk's CH distances with V0's arithmetic (all loads issued together: one
+        // memory latency) and keep the first that equals the winning distance
+        const float best = __uint_as_float((uint32_t)(key >> 32));
+        const int cstart = (int)((int64_t)(uint32_t)(key & 0xFFFFFFFFull) - index_base);
+        float rv[CH][K];
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) {
+            const int j = cstart + cc < n ? cstart + cc : n - 1;   // (clamped: the loads stay unconditional)
+#pragma unroll
+            for (int t = 0; t < K; ++t) rv[cc][t] = r[(size_t)j * K + t];
+        }
+        int bidx = cstart;
+#pragma unroll
+        for (int cc = CH - 1; cc >= 0; --cc) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int t = 0; t < K; ++t) sum = v0_step(sum, qrow[t], rv[cc][t]);
+            if (sum == best && cstart + cc < n) bidx = cstart + cc;   // descending: the lowest index wins
+        }
+        key = pack_key(best, (uint32_t)(index_base + bidx));
+    }
+    keys[qi] = key;
+    if (mg.idx_out) {
+        mg.idx_out[qi] = (int)(uint32_t)(key & 0xFFFFFFFFull);   // NNS_KEY_NONE -> 0, as V0
+        if (mg.dist_out) mg.dist_out[qi] = __uint_as_float((uint32_t)(key >> 32));
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(64 * K1A_MAXNW) void exact_lane_query_kernel(
     int m, int n, int refs_per_split, const float *__restrict__ q,
-    const float *__restrict__ r, int64_t index_base, nns_key *__restrict__ keys,
-    int use_atomic)
+    const float *__restrict__ r, int64_t index_base, nns_key *__restrict__ keys, const K1aMerge mg)
 {
     constexpr int CH = K1aChunk<K>::value;
     constexpr int NF = CH * K;                       // floats per chunk (multiple of 8)
     constexpr int TILE = K1A_LDS_FLOATS / K / CH * CH;   // refs per LDS tile (multiple of CH)
+    constexpr int QW = 64 * K1A_QPL;                 // queries per workgroup
     __shared__ __attribute__((aligned(16))) float sref[TILE * K];
+    __shared__ nns_key wkeys[K1A_MAXNW][QW];
+    __shared__ int s_last;
+    const int nthreads = blockDim.x, nw = nthreads >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j0 = blockIdx.y * refs_per_split;
     int j1 = j0 + refs_per_split;
     if (j1 > n) j1 = n;
@@ -156,26 +226,25 @@ __global__ __launch_bounds__(256) void exact_lane_query_kernel(
     int qi[K1A_QPL];
     float qv[K1A_QPL][K];
     float best[K1A_QPL];
-    int bidx[K1A_QPL];
+    int bchunk[K1A_QPL];   // first ref of the chunk the best distance came from
 #pragma unroll
     for (int u = 0; u < K1A_QPL; ++u) {
-        qi[u] = (blockIdx.x * K1A_QPL + u) * 256 + threadIdx.x;
+        qi[u] = blockIdx.x * QW + u * 64 + lane;
 #pragma unroll
         for (int t = 0; t < K; ++t) qv[u][t] = (qi[u] < m) ? q[(size_t)qi[u] * K + t] : 0.0f;
         best[u] = __builtin_inff();
-        bidx[u] = 0;
+        bchunk[u] = j0;
     }
 
     for (int t0 = j0; t0 < j1; t0 += TILE) {
         const int cnt = (j1 - t0) < TILE ? (j1 - t0) : TILE;
         __syncthreads();
-        for (int e = threadIdx.x; e < cnt * K; e += 256) sref[e] = r[(size_t)t0 * K + e];   // coalesced
+        for (int e = threadIdx.x; e < cnt * K; e += nthreads) sref[e] = r[(size_t)t0 * K + e];   // coalesced
+        // a ragged last chunk is padded with NaN coordinates: its distances are NaN, never selected
+        const int padded = (cnt + CH - 1) / CH * CH;   // <= TILE (a multiple of CH)
+        for (int e = cnt * K + threadIdx.x; e < padded * K; e += nthreads) sref[e] = __builtin_nanf("");
         __syncthreads();
-        int c = 0;
-        // Chunked scan: per pair only the 3K-1 distance ops + one v_min; the index of a new
-        // minimum is recovered in a (rare, wave-uniform) branch.  Ascending j and strict '<'
-        // keep V0's first-minimum rule inside the lane.
-        for (; c + CH <= cnt; c += CH) {
+        for (int c = wave * CH; c < cnt; c += nw * CH) {
             float cf[NF];
             const float4 *src = reinterpret_cast<const float4 *>(sref + c * K);   // uniform address
 #pragma unroll
@@ -199,97 +268,127 @@ __global__ __launch_bounds__(256) void exact_lane_query_kernel(
                 float cmin = d[0];
 #pragma unroll
                 for (int cc = 1; cc < CH; ++cc) cmin = fminf(cmin, d[cc]);   // NaN-ignoring min
-                const bool imp = cmin < best[u];                             // false for NaN / INF
-                if (__builtin_amdgcn_ballot_w64(imp) != 0ull) {
-                    if (imp) {
-                        best[u] = cmin;
-#pragma unroll
-                        for (int cc = CH - 1; cc >= 0; --cc)
-                            if (d[cc] == cmin) bidx[u] = t0 + c + cc;   // lowest index in the chunk wins
-                    }
-                }
-            }
-        }
-        for (; c < cnt; ++c) {   // ragged tail of the tile
-#pragma unroll
-            for (int u = 0; u < K1A_QPL; ++u) {
-                float sum = 0.0f;
-#pragma unroll
-                for (int t = 0; t < K; ++t) sum = v0_step(sum, qv[u][t], sref[c * K + t]);
-                if (best[u] > sum) {
-                    best[u] = sum;
-                    bidx[u] = t0 + c;
-                }
+                const bool imp = cmin < best[u];                             // false for NaN / INF; strict: first chunk wins
+                best[u] = imp ? cmin : best[u];
+                bchunk[u] = imp ? t0 + c : bchunk[u];
             }
         }
     }
+    // ---- the workgroup's waves: packed keys through LDS --------------------------------------------
+#pragma unroll
+    for (int u = 0; u < K1A_QPL; ++u) wkeys[wave][u * 64 + lane] = make_key(best[u], index_base + bchunk[u]);
+    __syncthreads();
+    // Wave w finishes the queries of register slots u = w, w + nw, ... (< QPL): query blockIdx.x * QW +
+    // u * 64 + lane, whose coordinates it holds in qv[u] (for the index recovery of write_final).
+    if (mg.splits <= 1) {
+#pragma unroll
+        for (int u = 0; u < K1A_QPL; ++u)
+            if (u % nw == wave && qi[u] < m) {   // (wave-uniform test)
+                nns_key mine = NNS_KEY_NONE;
+                for (int w = 0; w < nw; ++w) {
+                    const nns_key o = wkeys[w][u * 64 + lane];
+                    mine = o < mine ? o : mine;
+                }
+                write_final<K>(mg, keys, qi[u], mine, qv[u], r, n, index_base);
+            }
+        return;
+    }
+    // ---- the ref splits of this query tile: memory-side atomicMin, last arriver finishes ------------
 #pragma unroll
     for (int u = 0; u < K1A_QPL; ++u)
-        if (qi[u] < m) {
-            const nns_key key = make_key(best[u], index_base + bidx[u]);
-            if (use_atomic == 1)
-                atomicMin((unsigned long long *)&keys[qi[u]], (unsigned long long)key);
-            else if (use_atomic == 2)
-                keys[(size_t)blockIdx.y * m + qi[u]] = key;   // per-split partial -> keys_colmin_kernel
-            else
-                keys[qi[u]] = key;
+        if (u % nw == wave && qi[u] < m) {
+            nns_key mine = NNS_KEY_NONE;
+            for (int w = 0; w < nw; ++w) {
+                const nns_key o = wkeys[w][u * 64 + lane];
+                mine = o < mine ? o : mine;
+            }
+            const nns_key old = __hip_atomic_fetch_min(&mg.acc[qi[u]], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(old));   // returning atomic: waiting for its value = it has been performed
         }
-}
-
-// keys[i] = min over the splits of part[s][i]: the second stage of K1a (the reference's V7
-// does this step on the host, core.cu:675-696).  Plain coalesced traffic instead of
-// `splits` contended 64-bit atomics per query.  Workgroup = 32 queries x 8 split lanes.
-__global__ __launch_bounds__(256) void keys_colmin_kernel(const nns_key *__restrict__ part, int m, int splits,
-                                                          nns_key *__restrict__ keys)
-{
-    __shared__ nns_key red[8][32];
-    const int qi = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int g = threadIdx.x >> 5;
-    nns_key best = NNS_KEY_NONE;
-    if (qi < m)
-        for (int s = g; s < splits; s += 8) {
-            const nns_key v = part[(size_t)s * m + qi];
-            best = v < best ? v : best;
-        }
-    red[g][threadIdx.x & 31] = best;
-    __syncthreads();
-    if (g == 0 && qi < m) {
-#pragma unroll
-        for (int i = 1; i < 8; ++i) {
-            const nns_key v = red[i][threadIdx.x];
-            best = v < best ? v : best;
-        }
-        keys[qi] = best;
+    __syncthreads();                   // every atomic of the workgroup is done before the arrival is counted
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(&mg.cnt[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == mg.splits - 1;
     }
+    __syncthreads();
+    if (!s_last) return;               // (workgroup-uniform)
+#pragma unroll
+    for (int u = 0; u < K1A_QPL; ++u)
+        if (u % nw == wave && qi[u] < m) {
+            const nns_key v = __hip_atomic_load(&mg.acc[qi[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&mg.acc[qi[u]], (nns_key)NNS_KEY_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+            write_final<K>(mg, keys, qi[u], v, qv[u], r, n, index_base);
+        }
+    if (threadIdx.x == 0) __hip_atomic_store(&mg.cnt[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// geometry of a K1a launch
+struct K1aPlan {
+    int qtiles, nw, splits, per;
+};
 template <int K>
-static int launch_k1a(int m, int n, const float *q, const float *r, int64_t base,
-                      nns_key *keys, nns_key *ws, size_t ws_keys, hipStream_t st)
+static K1aPlan k1a_plan(int m, int n)
 {
-    const int qtiles = divup(m, 256 * K1A_QPL);
-    const int qwaves = divup(m, 64 * K1A_QPL);
-    // enough waves to fill 256 CUs x 4 SIMDs a few times over, >= 256 refs per split
-    int splits = divup(NNS_K1A_WAVES, qwaves);
-    const int max_splits = divup(n, 256);
+    constexpr int CH = K1aChunk<K>::value;
+    K1aPlan p;
+    p.qtiles = divup(m, 64 * K1A_QPL);
+    // waves per workgroup: as many as it takes to reach the target wave count with ONE ref range per query
+    // tile, up to K1A_MAXNW (more waves per workgroup = fewer ref splits = fewer cross-workgroup merges),
+    // each wave with at least 4 chunks of work per LDS tile
+    int nw = divup(NNS_K1A_WAVES, p.qtiles);
+    if (nw > K1A_MAXNW) nw = K1A_MAXNW;
+    while (nw > 1 && (int64_t)nw * 4 * CH > n) nw >>= 1;
+    if (nw < 1) nw = 1;
+    p.nw = nw;
+    // ref splits: the rest of the way to the target, >= 64 refs per wave
+    int splits = divup(NNS_K1A_WAVES, p.qtiles * nw);
+    const int max_splits = divup(n, 64 * nw);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
     int per = divup(n, splits);
-    per = divup(per, K1aChunk<K>::value) * K1aChunk<K>::value;
-    splits = divup(n, per);
-    if (splits > 1 && ws && ws_keys >= (size_t)splits * m) {
-        // two-stage: per-split partial keys, then a column min
-        hipLaunchKernelGGL(exact_lane_query_kernel<K>, dim3(qtiles, splits), dim3(256), 0, st,
-                           m, n, per, q, r, base, ws, 2);
-        NNS_HIP(hipGetLastError());
-        hipLaunchKernelGGL(keys_colmin_kernel, dim3(divup(m, 32)), dim3(256), 0, st, ws, m, splits, keys);
-        NNS_HIP(hipGetLastError());
-        return NNS_OK;
+    per = divup(per, CH) * CH;
+    p.per = per;
+    p.splits = divup(n, per);
+    return p;
+}
+
+// workspace of the cross-split merge, in keys (8-byte units): the accumulator + the counters
+template <int K>
+static size_t k1a_workspace_keys(int m, int n)
+{
+    const K1aPlan p = k1a_plan<K>(m, n);
+    if (p.splits <= 1) return 0;
+    return (size_t)m + ((size_t)p.qtiles * sizeof(int) + 7) / 8 + 1;
+}
+
+template <int K>
+static int launch_k1a(int m, int n, const float *q, const float *r, int64_t base,
+                      nns_key *keys, nns_key *ws, size_t ws_keys, bool ws_fresh, int *idx_out, float *dist_out,
+                      hipStream_t st)
+{
+    K1aPlan p = k1a_plan<K>(m, n);
+    K1aMerge mg{};
+    mg.idx_out = idx_out;
+    mg.dist_out = dist_out;
+    if (p.splits > 1) {
+        if (!ws || ws_keys < k1a_workspace_keys<K>(m, n)) {
+            // no workspace (allocation failed): one ref range per query tile — slower, still one launch
+            p.splits = 1;
+            p.per = divup(n, K1aChunk<K>::value) * K1aChunk<K>::value;
+        } else {
+            mg.acc = ws;
+            mg.cnt = reinterpret_cast<int *>(ws + m);
+            // accumulator and counters re-arm themselves; a fresh (or re-laid-out) workspace is armed once
+            if (ws_fresh) {
+                NNS_TRY(launch_keys_fill(mg.acc, m, NNS_KEY_NONE, st));
+                NNS_HIP(hipMemsetAsync(mg.cnt, 0, (size_t)p.qtiles * sizeof(int), st));
+            }
+        }
     }
-    if (splits > 1) NNS_TRY(launch_keys_fill(keys, m, NNS_KEY_NONE, st));
-    hipLaunchKernelGGL(exact_lane_query_kernel<K>, dim3(qtiles, splits), dim3(256), 0, st,
-                       m, n, per, q, r, base, keys, splits > 1 ? 1 : 0);
+    mg.splits = p.splits;
+    hipLaunchKernelGGL(exact_lane_query_kernel<K>, dim3(p.qtiles, p.splits), dim3(64 * p.nw), 0, st,
+                       m, n, p.per, q, r, base, keys, mg);
     NNS_HIP(hipGetLastError());
     return NNS_OK;
 }
@@ -613,29 +712,34 @@ static int check_k(int k)
     return NNS_OK;
 }
 
+static bool k1a_dim(int k) { return k == 1 || k == 2 || k == 3 || k == 4 || k == 8 || k == 16; }
+
 size_t exact_workspace_keys(int k, int m, int n)
 {
-    // upper bound of splits * m for K1a (see launch_k1a)
-    if (m < 64 || !(k == 1 || k == 2 || k == 3 || k == 4 || k == 8 || k == 16)) return 0;
-    int splits = divup(NNS_K1A_WAVES, divup(m, 64 * K1A_QPL));
-    const int max_splits = divup(n, 256);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 2) return 0;
-    return (size_t)(splits + 1) * m;
+    if (m < 64 || !k1a_dim(k)) return 0;
+    switch (k) {
+    case 1: return k1a_workspace_keys<1>(m, n);
+    case 2: return k1a_workspace_keys<2>(m, n);
+    case 3: return k1a_workspace_keys<3>(m, n);
+    case 4: return k1a_workspace_keys<4>(m, n);
+    case 8: return k1a_workspace_keys<8>(m, n);
+    default: return k1a_workspace_keys<16>(m, n);
+    }
 }
 
 int launch_exact_search(int k, int m, int n, const float *q, const float *r,
-                        int64_t index_base, nns_key *keys, nns_key *ws, size_t ws_keys, hipStream_t st)
+                        int64_t index_base, nns_key *keys, nns_key *ws, size_t ws_keys, bool ws_fresh,
+                        int *idx_out, float *dist_out, hipStream_t st)
 {
     // K1a needs enough queries to fill lanes; its query lives in K registers
     if (m >= 64) {
         switch (k) {
-        case 1: return launch_k1a<1>(m, n, q, r, index_base, keys, ws, ws_keys, st);
-        case 2: return launch_k1a<2>(m, n, q, r, index_base, keys, ws, ws_keys, st);
-        case 3: return launch_k1a<3>(m, n, q, r, index_base, keys, ws, ws_keys, st);
-        case 4: return launch_k1a<4>(m, n, q, r, index_base, keys, ws, ws_keys, st);
-        case 8: return launch_k1a<8>(m, n, q, r, index_base, keys, ws, ws_keys, st);
-        case 16: return launch_k1a<16>(m, n, q, r, index_base, keys, ws, ws_keys, st);
+        case 1: return launch_k1a<1>(m, n, q, r, index_base, keys, ws, ws_keys, ws_fresh, idx_out, dist_out, st);
+        case 2: return launch_k1a<2>(m, n, q, r, index_base, keys, ws, ws_keys, ws_fresh, idx_out, dist_out, st);
+        case 3: return launch_k1a<3>(m, n, q, r, index_base, keys, ws, ws_keys, ws_fresh, idx_out, dist_out, st);
+        case 4: return launch_k1a<4>(m, n, q, r, index_base, keys, ws, ws_keys, ws_fresh, idx_out, dist_out, st);
+        case 8: return launch_k1a<8>(m, n, q, r, index_base, keys, ws, ws_keys, ws_fresh, idx_out, dist_out, st);
+        case 16: return launch_k1a<16>(m, n, q, r, index_base, keys, ws, ws_keys, ws_fresh, idx_out, dist_out, st);
         default: break;
         }
     }
@@ -644,7 +748,9 @@ int launch_exact_search(int k, int m, int n, const float *q, const float *r,
     const int qt = pick_qt(k, m);
     int groups = divup(m, qt);
     if (groups > 4096) groups = 4096;   // grid.y strides over the rest
-    return launch_k1b<float>(k, n, q, r, nullptr, nullptr, m, qt, groups, index_base, keys, st);
+    NNS_TRY(launch_k1b<float>(k, n, q, r, nullptr, nullptr, m, qt, groups, index_base, keys, st));
+    if (idx_out) NNS_TRY(launch_keys_unpack(keys, m, idx_out, dist_out, st));
+    return NNS_OK;
 }
 
 int launch_exact_search_bf16(int k, int m, int n, const uint16_t *q, const uint16_t *r,

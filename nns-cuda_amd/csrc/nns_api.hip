@@ -38,6 +38,11 @@ static size_t norm_bytes(const FilterGeom &g, int pts_pad) { return ((size_t)pts
 // below this many queries the AUTO path skips the MFMA filter (and, in the whole-call
 // entry points, its ref pre-pass too)
 static const int kTinyM = 64;
+// ... and a small problem in a dimensionality the lane-per-query exact kernel is instantiated for (8, 16)
+// is faster there than through the filter's fixed costs (K2 on both clouds, filter ramp, K5: ~55 us):
+// the reference driver's 16-D 1024 x 1024 sample (main.cu:44) takes 9 us instead of 57
+static const int64_t kSmallPairs = (int64_t)1 << 24;
+static bool small_exact(int k, int64_t m, int64_t n) { return (k == 8 || k == 16) && m >= kTinyM && m * n <= kSmallPairs; }
 // deepest dimensionality the MFMA filter tiles (bf16 operands; fp32 operands: 256)
 static const int kMaxFilterK = 512;
 
@@ -78,6 +83,8 @@ struct nns_index {
     // exact path: per-split partial keys of K1a
     nns_key *exact_ws = nullptr;
     size_t exact_ws_keys = 0;
+    int exact_ws_m = 0;
+    bool exact_ws_fresh = false;   // (re)allocated since the last K1a launch: its arrival counters need zeroing once
 
     // NNS_PROFILE: a ring of event sets, one per search (refresh + search = one step), so that a
     // caller can time many steps back to back and read the averages once, without a device
@@ -385,8 +392,12 @@ static void profile_advance(nns_index *ix, int path)
     if (ix->ev_count < kEvRing) ++ix->ev_count;
 }
 
-static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, nns_key *keys_dev, void *stream)
+// idx_dev / dist_dev (optional): also leave the unpacked indices / distances (K1a writes them in its one
+// launch; every other path appends the unpack kernel)
+static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, nns_key *keys_dev, void *stream,
+                             int *idx_dev = nullptr, float *dist_dev = nullptr)
 {
+    bool unpacked = false;
     if (ix && ix->bf16 != bf16) {
         set_error("nns_index_search: query dtype does not match the index (%s index)", ix->bf16 ? "bf16" : "fp32");
         return NNS_ERR_INVALID;
@@ -402,7 +413,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
 
     // A handful of queries cannot fill MFMA tiles (they are padded to 256): the ref stream
     // is then HBM-bound and the exact lane-per-ref kernel is the faster path (AUTO only).
-    const bool tiny = (ix->flags & NNS_PATH_MASK) == NNS_PATH_AUTO && m < kTinyM;
+    const bool tiny = (ix->flags & NNS_PATH_MASK) == NNS_PATH_AUTO && (m < kTinyM || (!bf16 && small_exact(ix->k, m, ix->n)));
     if (ix->path != NNS_PATH_MFMA || ix->refs_bad || tiny) {
         if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_BEGIN], st);
         if (bf16)
@@ -416,12 +427,22 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
                 pool_free(ix->exact_ws);
                 ix->exact_ws = nullptr;
                 ix->exact_ws_keys = 0;
-                if (pool_alloc(&ix->exact_ws, need * sizeof(nns_key)) == hipSuccess) ix->exact_ws_keys = need;
-                else (void)hipGetLastError();   // no workspace: K1a falls back to atomics
+                if (pool_alloc(&ix->exact_ws, need * sizeof(nns_key)) == hipSuccess) {
+                    ix->exact_ws_keys = need;
+                    ix->exact_ws_fresh = true;
+                } else {
+                    (void)hipGetLastError();   // no workspace: K1a runs one ref range per query tile
+                }
             }
+            // (the workspace layout depends on m: a different m re-lays the counters out -> zero them again)
+            if (m != ix->exact_ws_m) ix->exact_ws_fresh = true;
+            ix->exact_ws_m = m;
             NNS_TRY(launch_exact_search(ix->k, m, ix->n, (const float *)q_dev, (const float *)ix->r_dev, ix->base,
-                                        keys_dev, ix->exact_ws, ix->exact_ws_keys, st));
+                                        keys_dev, ix->exact_ws, ix->exact_ws_keys, ix->exact_ws_fresh, idx_dev, dist_dev, st));
+            ix->exact_ws_fresh = false;
+            unpacked = idx_dev != nullptr;
         }
+        if (idx_dev && !unpacked) NNS_TRY(launch_keys_unpack(keys_dev, m, idx_dev, dist_dev, st));
         if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_END], st);
         ix->last_path = NNS_PATH_EXACT;
         ix->searched = true;
@@ -472,10 +493,9 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
     else
         NNS_TRY(launch_exact_listed(ix->k, ix->n, (const float *)q_dev, (const float *)ix->r_dev, ix->amb_list,
                                     &ix->scal->amb_count, m, ix->base, keys_dev, st));
-    if (prof) {
-        (void)hipEventRecord(ix->evr[ix->ev_slot][EV_RERANK], st);
-        (void)hipEventRecord(ix->evr[ix->ev_slot][EV_END], st);
-    }
+    if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_RERANK], st);
+    if (idx_dev) NNS_TRY(launch_keys_unpack(keys_dev, m, idx_dev, dist_dev, st));
+    if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_END], st);
     ix->last_path = NNS_PATH_MFMA;
     ix->searched = true;
     profile_advance(ix, NNS_PATH_MFMA);
@@ -490,6 +510,16 @@ int nns_index_search(nns_index *ix, int m, const float *q_dev, nns_key *keys_dev
 int nns_index_search_bf16(nns_index *ix, int m, const uint16_t *q_dev, nns_key *keys_dev, void *stream)
 {
     return index_search_impl(ix, m, q_dev, 1, keys_dev, stream);
+}
+
+int nns_index_search_indices(nns_index *ix, int m, const void *q_dev, nns_key *keys_dev, int *idx_dev,
+                             float *dist_dev, void *stream)
+{
+    if (!idx_dev) {
+        set_error("nns_index_search_indices: idx_dev is null");
+        return NNS_ERR_INVALID;
+    }
+    return index_search_impl(ix, m, q_dev, ix ? ix->bf16 : 0, keys_dev, stream, idx_dev, dist_dev);
 }
 
 int nns_index_stats(nns_index *ix, nns_stats *out)
@@ -642,7 +672,7 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
     NNS_TRY(ensure_device_ok(device));
     if (num_shards < 1) num_shards = 1;
     if (num_shards > n) num_shards = n;   // the reference clamps GPUs to n (core.cu:771-772)
-    if ((flags & NNS_PATH_MASK) == NNS_PATH_AUTO && m < kTinyM) flags |= NNS_PATH_EXACT;
+    if ((flags & NNS_PATH_MASK) == NNS_PATH_AUTO && (m < kTinyM || (!bf16 && small_exact(k, m, n)))) flags |= NNS_PATH_EXACT;
 
     char *q_d = nullptr, *r_d = nullptr, *r_t = nullptr;
     float *dist_d = nullptr;
@@ -690,7 +720,9 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             if (cnt <= 0) break;
             rc = index_create_impl(&ix, device, k, cnt, r_d + (size_t)beg * k * esz, bf16, beg, flags, st);
             if (rc != NNS_OK) break;
-            rc = index_search_impl(ix, m, q_d, bf16, first ? keys : keys_tmp, st);
+            // one shard: indices (and distances) straight out of the search (K1a: the same launch)
+            rc = num_shards == 1 ? index_search_impl(ix, m, q_d, bf16, keys, st, idx_d, dist_d)
+                                 : index_search_impl(ix, m, q_d, bf16, first ? keys : keys_tmp, st);
             if (rc == NNS_OK && !first) rc = nns_keys_min(keys, keys_tmp, m, st);
             if (rc == NNS_OK && hipStreamSynchronize(st) != hipSuccess) {
                 set_error("nns_search_f32: kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
@@ -701,7 +733,7 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             first = false;
         }
         if (rc != NNS_OK) break;
-        rc = nns_keys_unpack(keys, m, idx_d, dist_d, st);
+        if (num_shards > 1) rc = nns_keys_unpack(keys, m, idx_d, dist_d, st);
         if (rc != NNS_OK) break;
         if (hipMemcpy(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
             (dist_out && hipMemcpy(dist_out, dist_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {

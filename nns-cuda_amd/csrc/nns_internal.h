@@ -184,11 +184,13 @@ int launch_keys_min(nns_key *inout, const nns_key *other, int m, hipStream_t st)
 int launch_keys_unpack(const nns_key *keys, int m, int *idx, float *dist, hipStream_t st);
 int launch_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset, hipStream_t st);
 // exact search of all m queries (K1a lane=query when k is small, else K1b)
-// ws: optional workspace of ws_keys keys (exact_workspace_keys) for the two-stage merge
+// ws: workspace of ws_keys keys (exact_workspace_keys) for K1a's in-kernel second stage; ws_fresh: it was
+// (re)allocated since the last launch (its arrival counters are then zeroed once; they re-arm themselves).
+// idx_out / dist_out (optional): also write the unpacked indices / distances (K1a: same launch).
 size_t exact_workspace_keys(int k, int m, int n);
 int launch_exact_search(int k, int m, int n, const float *q, const float *r,
-                        int64_t index_base, nns_key *keys, nns_key *ws, size_t ws_keys,
-                        hipStream_t st);
+                        int64_t index_base, nns_key *keys, nns_key *ws, size_t ws_keys, bool ws_fresh,
+                        int *idx_out, float *dist_out, hipStream_t st);
 // exact scan of the queries listed in qlist[0 .. *qcount) (device memory); keys
 // of listed queries must hold NNS_KEY_NONE on entry (atomic-min merge).
 int launch_exact_listed(int k, int n, const float *q, const float *r,

@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "nns_last_error", "nns_version", "nns_selftest_mfma",
     "nns_index_create_bf16", "nns_index_search_bf16", "nns_search_bf16_ex", "nns_search_f32_multi",
     "nns_trim", "nns_warmup", "nns_shutdown", "nns_search_bf16_multi",
-    "nns_index_near_ties", "nns_tau_consts",
+    "nns_index_near_ties", "nns_tau_consts", "nns_index_search_indices",
     "nns_comm_unique_id", "nns_comm_create", "nns_comm_size", "nns_comm_allreduce_min", "nns_comm_destroy",
 )
 NNS_COMM_ID_BYTES = 128
@@ -100,6 +100,7 @@ def _load() -> ctypes.CDLL:
     lib.nns_index_refresh.argtypes = [c_vp, c_vp]
     lib.nns_index_search.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
     lib.nns_index_stats.argtypes = [c_vp, ctypes.POINTER(nns_stats)]
+    lib.nns_index_search_indices.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
     lib.nns_index_near_ties.argtypes = [c_vp, c_vp, c_int, ctypes.POINTER(c_int)]
     lib.nns_tau_consts.argtypes = [c_int, ctypes.c_float, ctypes.c_float, c_int, c_vp]
     lib.nns_keys_min.argtypes = [c_vp, c_vp, c_int, c_vp]
@@ -317,6 +318,23 @@ class Index:
     def search(self, queries, return_distances: bool = False, stream=None):
         keys = self.search_keys(queries, stream=stream)
         return keys_unpack(keys, return_distances=return_distances, stream=stream)
+
+    def search_indices(self, queries, keys=None, idx=None, dist=None, stream=None):
+        """nns_index_search_indices: keys AND unpacked int32 indices (and, if `dist` is given,
+        distances) of a single-shard search in as few launches as the path allows."""
+        import torch
+        if queries.dtype != self.refs.dtype or queries.dim() != 2 or not queries.is_contiguous() \
+                or queries.shape[1] != self.k:
+            raise ValueError("queries must be a contiguous [m][k] tensor of the index's dtype")
+        m = queries.shape[0]
+        if keys is None:
+            keys = torch.empty(m, dtype=torch.int64, device=queries.device)
+        if idx is None:
+            idx = torch.empty(m, dtype=torch.int32, device=queries.device)
+        _check(lib.nns_index_search_indices(self._h, m, queries.data_ptr(), keys.data_ptr(), idx.data_ptr(),
+                                            dist.data_ptr() if dist is not None else None, _stream_ptr(stream)),
+               "nns_index_search_indices")
+        return idx
 
     def stats(self) -> dict:
         st = nns_stats()

@@ -236,7 +236,9 @@ def test_filter_true_list_overflow_falls_back(pkg, orc):
 def test_low_dim_shapes_exact_path(pkg, orc):
     rng = np.random.default_rng(9)
     for (m, n, k) in [(4096, 8192, 3), (64, 100000, 3), (1000, 5000, 16), (63, 777, 2), (5, 50000, 8),
-                      (1, 65536, 16), (300, 3000, 7)]:
+                      (1, 65536, 16), (300, 3000, 7),
+                      # a handful of refs: one wave per workgroup must still finish BOTH query slots of a lane
+                      (1000, 1, 8), (1000, 5, 3), (513, 31, 16), (2049, 64, 4), (200, 33, 1)]:
         q = rng.random((m, k), dtype=np.float32)
         r = rng.random((n, k), dtype=np.float32)
         _check(pkg, orc, q, r, paths=("auto",), shards=(1, 4))
@@ -570,7 +572,10 @@ def test_filter_k32_tile_shapes(pkg, orc, shape):
     ix = pkg.Index(torch.from_numpy(r).cuda())
     ix.search(torch.from_numpy(q).cuda())
     st = ix.stats()
-    assert st["path"] == 2 and st["k_tile"] == (16 if k <= 16 else 32), st
+    if k in (8, 16) and m * n <= (1 << 24):     # small problems in a K1a dimensionality stay on the exact kernel under AUTO
+        assert st["path"] == 1, st
+    else:
+        assert st["path"] == 2 and st["k_tile"] == (16 if k <= 16 else 32), st
     ix.close()
 
 
@@ -1041,3 +1046,37 @@ def test_bench_self_launch_rehearsal():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["verified_vs_unsharded"] is True
     assert d["exchange"]["matches_torch_all_reduce"] is True and d["exchange"]["queries_won_sum_over_ranks"] >= d["config"]["m"]
+
+
+def test_search_indices_fused_unpack_and_k1a_rearm(pkg, orc):
+    """nns_index_search_indices: keys + unpacked indices / distances from one call on every path, and K1a's
+    in-kernel second stage across repeated launches on the same index (its arrival counters must re-arm),
+    across different query counts (the workspace is laid out again) and ragged ref counts."""
+    rng = np.random.default_rng(97)
+    for (m, n, k) in [(4096, 65536, 3), (700, 30001, 3), (64, 100003, 2), (1000, 5000, 16), (300, 7000, 128), (100, 3000, 7)]:
+        r = rng.random((n, k), dtype=np.float32)
+        r[n - 1] = r[1]                                   # a late duplicate: the lower index must win
+        rd = torch.from_numpy(r).cuda()
+        ix = pkg.Index(rd)
+        for mm in (m, max(64, m // 3), m):               # same index, three query counts
+            q = rng.random((mm, k), dtype=np.float32)
+            q[0] = r[1]
+            qd = torch.from_numpy(q).cuda()
+            want_idx, want_dist = orc.v0_search(q, r, threads=8)
+            for rep in range(3):                          # repeated launches: counters re-armed by the kernel
+                keys = torch.empty(mm, dtype=torch.int64, device="cuda")
+                dist = torch.empty(mm, dtype=torch.float32, device="cuda")
+                idx = ix.search_indices(qd, keys=keys, dist=dist)
+                torch.cuda.synchronize()
+                assert np.array_equal(idx.cpu().numpy(), want_idx), (m, n, k, mm, rep)
+                assert np.array_equal(_bits(dist.cpu().numpy()), _bits(want_dist))
+                kk = keys.cpu().numpy()
+                assert np.array_equal((kk & 0xFFFFFFFF).astype(np.int32), want_idx)
+        ix.close()
+    # bf16 index through the same entry point
+    q = orc.round_bf16(rng.random((200, 64), dtype=np.float32))
+    r = orc.round_bf16(rng.random((5000, 64), dtype=np.float32))
+    ix = pkg.Index(torch.from_numpy(r).cuda().to(torch.bfloat16))
+    idx = ix.search_indices(torch.from_numpy(q).cuda().to(torch.bfloat16))
+    assert np.array_equal(idx.cpu().numpy(), orc.v0_search(q, r, threads=8)[0])
+    ix.close()
