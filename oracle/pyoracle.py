@@ -22,6 +22,7 @@ _o.v0_search.argtypes = [_i, _i, _i, _vp, _vp, _vp, _vp]
 _o.v0_search_omp.argtypes = [_i, _i, _i, _vp, _vp, _vp, _vp, _i]
 _o.v0_search_sharded.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _vp]
 _o.kdtree_search.argtypes = [_i, _i, _i, _vp, _vp, _vp, _vp, _i]
+_o.octree_search.argtypes = [_i, _i, _i, _vp, _vp, _vp, _vp, _i]
 _o.v0_pair_distance.argtypes = [_i, _vp, _vp]
 _o.v0_pair_distance.restype = ctypes.c_float
 _o.ref_recipe_seed.argtypes = [ctypes.c_uint]
@@ -74,6 +75,19 @@ def kdtree_search(q, r, threads: int = 1):
     rc = _o.kdtree_search(k, m, n, q.ctypes.data, r.ctypes.data, idx.ctypes.data, dist.ctypes.data, threads)
     if rc != 0:
         raise RuntimeError(f"kdtree_search failed ({rc})")
+    return idx, dist
+
+
+def octree_search(q, r, threads: int = 1):
+    """(indices, V0 distances) by the exact octree comparator (oracle/octree.c; 3-D, finite inputs only)."""
+    q, r = _f32(q), _f32(r)
+    m, k = q.shape
+    n = r.shape[0]
+    idx = np.empty(m, np.int32)
+    dist = np.empty(m, np.float32)
+    rc = _o.octree_search(k, m, n, q.ctypes.data, r.ctypes.data, idx.ctypes.data, dist.ctypes.data, threads)
+    if rc != 0:
+        raise RuntimeError(f"octree_search failed ({rc})")
     return idx, dist
 
 

@@ -142,3 +142,34 @@ def test_kdtree_comparator_equals_v0(k):
         got_idx, got_dist = orc.kdtree_search(q, r, threads=4)
         assert np.array_equal(got_idx, want_idx)
         assert np.array_equal(got_dist.view(np.uint32), want_dist.view(np.uint32))
+
+
+def test_octree_comparator_equals_v0(orc):
+    """oracle/octree.c (the reference's V12 family — CPU octree, 3-D only — as an additional CPU
+    comparator, with V12's point-indexing bug fixed): the same indices and distance bits as V0 on
+    uniform, clustered, duplicated (lowest index wins), degenerate (all points on a plane / one point)
+    and offset clouds."""
+    rng = np.random.default_rng(3112)
+    cases = []
+    q = rng.random((500, 3), dtype=np.float32)
+    r = rng.random((20000, 3), dtype=np.float32)
+    cases.append((q, r))
+    c = rng.random((6, 3), dtype=np.float32) * 50
+    cases.append(((c[rng.integers(0, 6, 300)] + rng.normal(0, 0.2, (300, 3))).astype(np.float32),
+                  (c[rng.integers(0, 6, 9000)] + rng.normal(0, 0.2, (9000, 3))).astype(np.float32)))
+    base = rng.random((700, 3), dtype=np.float32)
+    rd = np.concatenate([base, base[:300], base])            # exact duplicates
+    cases.append((base[:200].copy(), rd))
+    flat = rng.random((4000, 3), dtype=np.float32)
+    flat[:, 2] = 0.25                                        # all refs in one plane
+    cases.append((rng.random((100, 3), dtype=np.float32), flat))
+    cases.append((rng.random((10, 3), dtype=np.float32), rng.random((1, 3), dtype=np.float32)))
+    cases.append(((1000.0 + rng.random((100, 3))).astype(np.float32), (1000.0 + rng.random((5000, 3))).astype(np.float32)))
+    cases.append((rng.random((50, 3), dtype=np.float32), np.tile(rng.random((1, 3), dtype=np.float32), (100, 1))))
+    for q, r in cases:
+        want_idx, want_dist = orc.v0_search(q, r, threads=4)
+        got_idx, got_dist = orc.octree_search(q, r, threads=4)
+        assert np.array_equal(got_idx, want_idx)
+        assert np.array_equal(got_dist.view(np.uint32), want_dist.view(np.uint32))
+    with pytest.raises(RuntimeError):
+        orc.octree_search(rng.random((4, 2), dtype=np.float32), rng.random((9, 2), dtype=np.float32))
