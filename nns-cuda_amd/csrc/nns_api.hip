@@ -10,6 +10,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 #include "nns_internal.h"
 
@@ -38,6 +41,9 @@ static size_t norm_bytes(const FilterGeom &g, int pts_pad) { return ((size_t)pts
 // below this many queries the AUTO path skips the MFMA filter (and, in the whole-call
 // entry points, its ref pre-pass too)
 static const int kTinyM = 64;
+// internal create flag (never set by callers: masked off at the C ABI): build the index without the
+// synchronising read-back of K2's max-|value| word; K5's device-side check then covers NaN / INF / huge refs
+static const unsigned kCreateNoSync = 1u << 30;
 // ... and a small problem in a dimensionality the lane-per-query exact kernel is instantiated for (8, 16)
 // is faster there than through the filter's fixed costs (K2 on both clouds, filter ramp, K5: ~55 us):
 // the reference driver's 16-D 1024 x 1024 sample (main.cu:44) takes 9 us instead of 57
@@ -285,6 +291,7 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
                 (void)hipEventRecord(ix->evr[ix->ev_slot][EV_R1], st);
                 ix->ev_refreshed[ix->ev_slot] = true;
             }
+            if (flags & kCreateNoSync) break;   // (pipelined whole call: stay asynchronous, K5 checks on the device)
             // index build is synchronous: learn whether the refs void the error bound
             DevScalars h{};
             if (hipMemcpyAsync(&h, ix->scal, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -307,13 +314,13 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
 int nns_index_create(nns_index **out, int device, int k, int n, const float *r_dev, int64_t index_base,
                      unsigned flags, void *stream)
 {
-    return index_create_impl(out, device, k, n, r_dev, 0, index_base, flags, stream);
+    return index_create_impl(out, device, k, n, r_dev, 0, index_base, flags & ~kCreateNoSync, stream);
 }
 
 int nns_index_create_bf16(nns_index **out, int device, int k, int n, const uint16_t *r_dev,
                           int64_t index_base, unsigned flags, void *stream)
 {
-    return index_create_impl(out, device, k, n, r_dev, 1, index_base, flags, stream);
+    return index_create_impl(out, device, k, n, r_dev, 1, index_base, flags & ~kCreateNoSync, stream);
 }
 
 int nns_index_refresh(nns_index *ix, void *stream)
@@ -657,6 +664,216 @@ int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const fl
     return rc;
 }
 
+// ---- pipelined upload of the whole-call entry points ---------------------------------------------------
+// The reference times alloc + H2D + kernels + D2H (main.cu:73-75).  A plain hipMemcpy of pageable memory
+// does not overlap the filter (its staging blits wait for the resident workgroups: measured), so large
+// MFMA-path calls upload through a ring of pinned staging buffers — filled by a few host threads, drained
+// by asynchronous (SDMA) copies on a copy stream — while the GPU already searches the first ref chunks.
+// Chunks grow geometrically (1/16, 1/8, 1/4, rest): the exposed upload is the queries + the small first
+// chunk, and most of the work runs on long ref streams.  Chunk results merge with nns_keys_min: the answer
+// is the unsharded one bit for bit.
+namespace {
+
+struct Stager {
+    static constexpr int NB = 4;
+    static constexpr size_t BUF = (size_t)16 << 20;
+    void *pinned[NB] = {};
+    hipEvent_t done[NB] = {};
+    bool used[NB] = {};
+    hipStream_t copy = nullptr;
+    int next = 0;
+    int threads = 4;
+    int device = 0;
+    bool ok = false;
+
+    int init()
+    {
+        for (int b = 0; b < NB; ++b)
+            if (hipHostMalloc(&pinned[b], BUF, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess)
+                return NNS_ERR_NOMEM;
+        if (hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) return NNS_ERR_HIP;
+        const unsigned hw = std::thread::hardware_concurrency();
+        threads = hw >= 8 ? 4 : (hw >= 4 ? 2 : 1);
+        ok = true;
+        return NNS_OK;
+    }
+    void destroy()
+    {
+        if (copy) {
+            (void)hipStreamSynchronize(copy);
+            (void)hipStreamDestroy(copy);
+        }
+        for (int b = 0; b < NB; ++b) {
+            if (done[b]) (void)hipEventDestroy(done[b]);
+            if (pinned[b]) (void)hipHostFree(pinned[b]);
+        }
+    }
+    // host -> device, asynchronous on the copy stream (returns once the last piece is STAGED, not landed)
+    int upload(void *dst, const void *src, size_t bytes)
+    {
+        for (size_t off = 0; off < bytes; off += BUF) {
+            const size_t piece = bytes - off < BUF ? bytes - off : BUF;
+            const int b = next;
+            next = (next + 1) % NB;
+            if (used[b] && hipEventSynchronize(done[b]) != hipSuccess) return NNS_ERR_HIP;   // the buffer's last copy has drained
+            const char *sp = (const char *)src + off;
+            char *dp = (char *)pinned[b];
+            const int nt = piece >= ((size_t)4 << 20) ? threads : 1;
+            if (nt > 1) {
+                std::vector<std::thread> th;
+                const size_t per = (piece / nt + 4095) & ~(size_t)4095;
+                for (int t = 1; t < nt; ++t) {
+                    const size_t a = (size_t)t * per, e = a + per < piece ? a + per : piece;
+                    if (a < e) th.emplace_back([=] { memcpy(dp + a, sp + a, e - a); });
+                }
+                memcpy(dp, sp, per < piece ? per : piece);
+                for (auto &t : th) t.join();
+            } else {
+                memcpy(dp, sp, piece);
+            }
+            if (hipMemcpyAsync((char *)dst + off, pinned[b], piece, hipMemcpyHostToDevice, copy) != hipSuccess ||
+                hipEventRecord(done[b], copy) != hipSuccess)
+                return NNS_ERR_HIP;
+            used[b] = true;
+        }
+        return NNS_OK;
+    }
+};
+
+Stager *g_stager = nullptr;
+std::mutex g_stager_mu;
+
+}  // namespace
+
+extern "C++" {
+namespace nns {
+// nns_shutdown: give the pinned staging ring back
+void stager_release()
+{
+    std::lock_guard<std::mutex> lk(g_stager_mu);
+    if (g_stager) {
+        g_stager->destroy();
+        delete g_stager;
+        g_stager = nullptr;
+    }
+}
+}  // namespace nns
+}  // extern "C++"
+
+// when the pipelined path pays: MFMA-path problems whose upload is worth hiding behind >= tens of ms of search
+static bool pipeline_pays(int k, int64_t m, int64_t n, int bf16, unsigned flags, size_t rbytes)
+{
+    if (flags & (NNS_REFS_SOA | NNS_PROFILE)) return false;
+    const unsigned path = flags & NNS_PATH_MASK;
+    if (path == NNS_PATH_EXACT) return false;
+    if (k < (bf16 ? 32 : 8) || k > kMaxFilterK) return false;
+    return rbytes >= ((size_t)128 << 20) && n >= (1 << 18) && m >= 8192;
+}
+
+static int search_host_pipelined(int k, int m, int n, const void *s_points, const void *r_points, int bf16,
+                                 int *idx_out, float *dist_out, unsigned flags, int device)
+{
+    const size_t esz = bf16 ? sizeof(uint16_t) : sizeof(float);
+    const size_t qb = (size_t)m * k * esz, rb = (size_t)n * k * esz;
+    char *q_d = nullptr, *r_d = nullptr;
+    float *dist_d = nullptr;
+    nns_key *keys = nullptr, *keys_tmp = nullptr;
+    int *idx_d = nullptr;
+    hipStream_t st = nullptr;          // compute: the default stream (orders with everything else of the call)
+    hipEvent_t landed = nullptr;
+    std::vector<nns_index *> shards;
+    // the pinned ring is kept for the life of the process (pinning 64 MiB costs milliseconds): one pipelined
+    // call at a time owns it, a concurrent caller takes the plain path
+    std::unique_lock<std::mutex> own(g_stager_mu, std::try_to_lock);
+    if (!own.owns_lock()) return NNS_ERR_UNSUPPORTED;
+    if (!g_stager || g_stager->device != device) {
+        if (g_stager) {
+            g_stager->destroy();
+            delete g_stager;
+            g_stager = nullptr;
+        }
+        Stager *ns = new (std::nothrow) Stager();
+        if (!ns || ns->init() != NNS_OK) {
+            if (ns) {
+                ns->destroy();
+                delete ns;
+            }
+            (void)hipGetLastError();
+            return NNS_ERR_UNSUPPORTED;    // no pinned memory: the plain path still works
+        }
+        ns->device = device;
+        g_stager = ns;
+    }
+    Stager &sg = *g_stager;
+    for (int b = 0; b < Stager::NB; ++b) sg.used[b] = false;
+    int rc = NNS_OK;
+    do {
+        if (hipEventCreateWithFlags(&landed, hipEventDisableTiming) != hipSuccess) {
+            rc = NNS_ERR_HIP;
+            break;
+        }
+        if (pool_alloc(&q_d, qb) != hipSuccess || pool_alloc(&r_d, rb) != hipSuccess ||
+            pool_alloc(&keys, (size_t)m * sizeof(nns_key)) != hipSuccess ||
+            pool_alloc(&keys_tmp, (size_t)m * sizeof(nns_key)) != hipSuccess ||
+            pool_alloc(&idx_d, (size_t)m * sizeof(int)) != hipSuccess ||
+            pool_alloc(&dist_d, (size_t)m * sizeof(float)) != hipSuccess) {
+            set_error("nns_search: device allocation failed");
+            rc = NNS_ERR_NOMEM;
+            break;
+        }
+        if ((rc = sg.upload(q_d, s_points, qb)) != NNS_OK) break;
+        // ref chunks: 1/16, 1/8, 1/4, the rest (multiples of 512 refs: whole ring slots at every tile depth)
+        int bounds[5] = {0, 0, 0, 0, n};
+        {
+            const int64_t unit = 512;
+            bounds[1] = (int)(((int64_t)n / 16 + unit - 1) / unit * unit);
+            bounds[2] = (int)(((int64_t)n * 3 / 16 + unit - 1) / unit * unit);
+            bounds[3] = (int)(((int64_t)n * 7 / 16 + unit - 1) / unit * unit);
+        }
+        bool first = true;
+        for (int c = 0; c < 4 && rc == NNS_OK; ++c) {
+            const int beg = bounds[c], cnt = bounds[c + 1] - bounds[c];
+            if (cnt <= 0) continue;
+            if ((rc = sg.upload(r_d + (size_t)beg * k * esz, (const char *)r_points + (size_t)beg * k * esz,
+                                (size_t)cnt * k * esz)) != NNS_OK)
+                break;
+            // the chunk (and, for the first one, the queries) has landed before its search starts
+            if (hipEventRecord(landed, sg.copy) != hipSuccess || hipStreamWaitEvent(st, landed, 0) != hipSuccess) {
+                rc = NNS_ERR_HIP;
+                break;
+            }
+            nns_index *ix = nullptr;
+            rc = index_create_impl(&ix, device, k, cnt, r_d + (size_t)beg * k * esz, bf16, beg, flags | kCreateNoSync, st);
+            if (rc != NNS_OK) break;
+            shards.push_back(ix);
+            rc = index_search_impl(ix, m, q_d, bf16, first ? keys : keys_tmp, st);
+            if (rc == NNS_OK && !first) rc = nns_keys_min(keys, keys_tmp, m, st);
+            first = false;
+        }
+        if (rc != NNS_OK) break;
+        rc = nns_keys_unpack(keys, m, idx_d, dist_d, st);
+        if (rc != NNS_OK) break;
+        if (hipMemcpy(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+            (dist_out && hipMemcpy(dist_out, dist_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
+            set_error("nns_search: kernel execution or D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = NNS_ERR_HIP;
+        }
+    } while (0);
+    if (rc == NNS_ERR_HIP && !*nns_last_error()) set_error("nns_search (pipelined): %s", hipGetErrorString(hipGetLastError()));
+    (void)hipDeviceSynchronize();   // the blocks go back to the pool: nothing may still use them
+    for (nns_index *ix : shards) nns_index_destroy(ix);
+    (void)hipStreamSynchronize(sg.copy);
+    if (landed) (void)hipEventDestroy(landed);
+    pool_free(q_d);
+    pool_free(r_d);
+    pool_free(keys);
+    pool_free(keys_tmp);
+    pool_free(idx_d);
+    pool_free(dist_d);
+    return rc;
+}
+
 static int search_host_impl(int k, int m, int n, const void *s_points, const void *r_points, int bf16,
                             int *idx_out, float *dist_out, int num_shards, unsigned flags, int device)
 {
@@ -673,6 +890,10 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
     if (num_shards < 1) num_shards = 1;
     if (num_shards > n) num_shards = n;   // the reference clamps GPUs to n (core.cu:771-772)
     if ((flags & NNS_PATH_MASK) == NNS_PATH_AUTO && (m < kTinyM || (!bf16 && small_exact(k, m, n)))) flags |= NNS_PATH_EXACT;
+    if (num_shards == 1 && pipeline_pays(k, m, n, bf16, flags, (size_t)n * k * esz)) {
+        const int prc = search_host_pipelined(k, m, n, s_points, r_points, bf16, idx_out, dist_out, flags, device);
+        if (prc != NNS_ERR_UNSUPPORTED) return prc;   // (UNSUPPORTED: ring busy / no pinned memory -> plain path)
+    }
 
     char *q_d = nullptr, *r_d = nullptr, *r_t = nullptr;
     float *dist_d = nullptr;

@@ -407,6 +407,7 @@ int nns_shutdown(void)
             for (ncclComm_t c : s.second.comms) (void)rccl().CommDestroy(c);
         cc.sets.clear();
     }
+    stager_release();
     (void)nns_trim();
     return NNS_OK;
 }

@@ -5,12 +5,12 @@ Run in the BUILD CONTAINER only (needs /root/reference to have been compiled int
 oracle/_ref/libv0ref.so by oracle/build_ref.sh).  Every expected output below is
 produced by the reference's OWN V0 (core.cu:11-54), never by our code:
 
-  golden_recipe.npz   the reference driver's first 8 samples (main.cu:38-47) drawn
+  golden_recipe.npz   the reference driver's ten samples (main.cu:38-51) drawn
                       with its data recipe (srand(1000), glibc rand(), queries then
                       refs: main.cu:10-13, 27-34, 54, 64).  Inputs are stored for the
-                      6 small samples; the two 1024x65536 samples store the expected
-                      indices plus an FNV-1a digest of the inputs (regenerated from
-                      the glibc stream at test time).
+                      6 small samples; the 1024x65536 and 1024x1048576 samples store the
+                      expected indices plus an FNV-1a digest of the inputs (regenerated
+                      from the glibc stream at test time).
   golden_cases.npz    adversarial cases (exact ties from duplicated refs, NaN / INF
                       rows, near-ties, clusters far from the origin, ragged sizes,
                       m = 1, n = 1, 128-D clouds) with inputs and expected indices.
@@ -27,7 +27,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import __graft_entry__ as graft  # noqa: E402
 
 SAMPLES = [(3, 1, 1024), (16, 1, 1024), (3, 1, 65536), (16, 1, 65536),
-           (3, 1024, 1024), (16, 1024, 1024), (3, 1024, 65536), (16, 1024, 65536)]
+           (3, 1024, 1024), (16, 1024, 1024), (3, 1024, 65536), (16, 1024, 65536),
+           (3, 1024, 1048576), (16, 1024, 1048576)]      # all ten of main.cu:38-51
 STORE_INPUT_LIMIT = 1 << 20   # floats
 
 

@@ -163,9 +163,9 @@ def test_golden_recipe_samples(pkg, orc, golden_dir):
 
 
 def test_golden_recipe_glibc_big_samples(pkg, orc, golden_dir):
-    """Samples 6 and 7 (1024 x 65536) regenerated from the glibc stream."""
+    """Samples 6 - 9 (1024 x 65536 and 1024 x 1048576) regenerated from the glibc stream."""
     z = np.load(f"{golden_dir}/golden_recipe.npz")
-    samples = [tuple(int(v) for v in z[f"s{i}_shape"]) for i in range(8)]
+    samples = [tuple(int(v) for v in z[f"s{i}_shape"]) for i in range(10)]
     for i, (k, m, n, q, r) in enumerate(orc.ref_recipe(samples, seed=1000)):
         fnv = z[f"s{i}_input_fnv"]
         if orc.fnv1a64(q) != int(fnv[0]) or orc.fnv1a64(r) != int(fnv[1]):
@@ -1080,3 +1080,31 @@ def test_search_indices_fused_unpack_and_k1a_rearm(pkg, orc):
     idx = ix.search_indices(torch.from_numpy(q).cuda().to(torch.bfloat16))
     assert np.array_equal(idx.cpu().numpy(), orc.v0_search(q, r, threads=8)[0])
     ix.close()
+
+
+@pytest.mark.timeout(600)
+def test_whole_call_pipelined_upload(pkg, orc):
+    """Large MFMA-path whole calls upload through the pinned staging ring while the first ref chunks are
+    already being searched (chunks of 1/16, 1/8, 1/4 and the rest, merged with the packed-key min): the
+    answer must be the unsharded V0 answer bit for bit — with exact cross-chunk ties, and with a NaN in a
+    late chunk (found by K5's device-side check, since the pipelined build never synchronises)."""
+    m, n, k = 8192, 262144 + 777, 128
+    q = orc.rng_uniform(m * k, 91, 0).reshape(m, k)
+    r = orc.rng_uniform(n * k, 91, m * k).reshape(n, k)
+    r[n - 5] = r[3]                      # cross-chunk exact tie: the lowest index (first chunk) must win
+    q[0] = r[3]
+    q[1] = r[n - 9]                      # exact hit in the last chunk
+    want_idx, want_dist = orc.v0_search(q, r, threads=16)
+    for rep in range(2):                 # second call: the cached staging ring and pooled workspaces
+        idx, dist = pkg.search(q, r, return_distances=True)
+        assert np.array_equal(idx, want_idx), rep
+        assert np.array_equal(_bits(dist), _bits(want_dist))
+    assert np.array_equal(pkg.cudaCall(k, m, n, q, r), want_idx)
+    assert np.array_equal(pkg.search(q, r, shards=3), want_idx)     # the plain (non-pipelined) path agrees
+    r2 = r.copy()
+    r2[200000, 7] = np.nan
+    with np.errstate(all="ignore"):
+        w2 = orc.v0_search(q, r2, threads=16)[0]
+    assert np.array_equal(pkg.search(q, r2), w2)
+    pkg.shutdown()                       # releases the pinned ring; the next call rebuilds it
+    assert np.array_equal(pkg.search(q, r), want_idx)

@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 SAMPLES = [(3, 1, 1024), (16, 1, 1024), (3, 1, 65536), (16, 1, 65536),
-           (3, 1024, 1024), (16, 1024, 1024), (3, 1024, 65536), (16, 1024, 65536)]
+           (3, 1024, 1024), (16, 1024, 1024), (3, 1024, 65536), (16, 1024, 65536),
+           (3, 1024, 1048576), (16, 1024, 1048576)]
 
 # first indices of the reference's V0 on its own srand(1000) stream
 SURVEY_FIRST = {0: [537], 1: [733], 2: [59136], 3: [41906],
@@ -43,12 +44,13 @@ def test_oracle_matches_golden_recipe_glibc_stream(orc, golden_dir):
         fnv = z[f"s{i}_input_fnv"]
         if orc.fnv1a64(q) != int(fnv[0]) or orc.fnv1a64(r) != int(fnv[1]):
             pytest.skip("libc rand() stream differs from the fixture's")
-        if m * n > (1 << 26) // 4 and k == 16:
+        if m * n > (1 << 26) // 4:
             idx, _ = orc.v0_search(q, r, threads=8)
         else:
             idx, _ = orc.v0_search(q, r)
         assert np.array_equal(idx, z[f"s{i}_idx"]), f"sample {i}"
-        assert idx[:len(SURVEY_FIRST[i])].tolist() == SURVEY_FIRST[i]
+        if i in SURVEY_FIRST:
+            assert idx[:len(SURVEY_FIRST[i])].tolist() == SURVEY_FIRST[i]
 
 
 def test_oracle_matches_golden_adversarial(orc, golden_dir):
