@@ -1,24 +1,28 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box: bench lines, rocprofv3 kernel stats, PMC passes.
 # usage (from the repo root, on the GPU box): bash tools/collect_profiles.sh <tag>
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# the driver-shaped default run: C3 headline + the also block (C1, C2, C5)
+timeout -k 10 400 python bench.py --steps 10 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_default.json
+echo "bench default: $(cut -c1-160 $OUT/bench_default.json)"
 for W in c3 c2 c5; do
-  timeout -k 10 300 python bench.py --workload $W --steps 10 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_$W.json
-  echo "bench $W: $(cut -c1-200 $OUT/bench_$W.json)"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- python3 bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats_$W.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- python3 bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline --no-also > $OUT/stats_$W.log 2>&1
   cp $OUT/stats_$W/*/*kernel_stats.csv $OUT/kernel_stats_$W.csv 2>/dev/null
+  echo "stats $W exit $?"
 done
-for W in c3 c5; do
+for W in c3 c5 c2; do
   for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
     D=$OUT/pmc_${W}_$(echo $C | cut -d" " -f1)
-    timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline > $D.log 2>&1
+    timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-also > $D.log 2>&1
     echo "pmc $W $C exit $?"
   done
 done
 timeout -k 10 300 ./nns-cuda_amd/nns_driver --repeat 3 > $OUT/driver.txt 2>&1
-timeout -k 10 300 python tools/wholecall_c3.py > $OUT/wholecall_c3.txt 2>&1
-cat $OUT/wholecall_c3.txt | grep -v amdgpu
+timeout -k 10 300 python tools/wholecall_c3.py 2>&1 | grep -v amdgpu > $OUT/wholecall_c3.txt
+timeout -k 10 300 python tools/probe_depths.py 2>&1 | grep -v amdgpu > $OUT/depths.txt
+timeout -k 10 300 python tools/probe_streams.py 2>&1 | grep -v amdgpu > $OUT/streams.txt
+cat $OUT/depths.txt
 ls $OUT
