@@ -64,19 +64,20 @@ enum {
 
 /* path selection flags (nns_index_create / nns_search_f32_ex) */
 enum {
-    NNS_PATH_AUTO = 0,   /* MFMA filter for 8 <= k <= 512 (bf16 points: 32..512) and >= 64 queries, exact kernels otherwise */
+    NNS_PATH_AUTO = 0,   /* MFMA filter for 8 <= k <= 1024 (bf16 points: 32..1024) and >= 64 queries (small 8- / 16-D
+                          * problems excepted), exact kernels otherwise */
     NNS_PATH_EXACT = 1,  /* exact per-pair kernels only (V1..V9 arithmetic re-expressed) */
     NNS_PATH_MFMA = 2,   /* -2*Q*R^T MFMA filter + exact re-rank (k padded to the tile K) */
     NNS_PATH_MASK = 3,
     NNS_PROFILE = 16,    /* record HIP-event timings per stage (adds syncs at read-out) */
     NNS_MULTI_VIRTUAL = 32, /* nns_search_f32_multi: allow more shards than GPUs (rehearsal) */
-    NNS_FILTER_BF16 = 128, /* OPT-IN, fp32 points only, k <= 512: run the MFMA filter on the centred points
+    NNS_FILTER_BF16 = 128, /* OPT-IN, fp32 points only, k <= 1024: run the MFMA filter on the centred points
                           * rounded to bf16 (v_mfma_f32_16x16x32_bf16: 16x the fp32 MFMA rate) with a margin tau
                           * widened by the rounding bound 2^-6 |x'||y'|, then re-rank the candidates with V0's fp32
                           * arithmetic on the ORIGINAL fp32 points as usual.  Indices and distances are the same
                           * bits as without the flag (the filter only decides which refs are re-ranked); queries
                           * whose candidate lists overflow fall back to the exact scan.  NNS_PATH_AUTO
-                          * takes this filter by itself only for 256 < k <= 512, where no fp32 tile exists (the
+                          * takes this filter by itself only for 256 < k <= 1024, where no fp32 tile exists (the
                           * alternative is the VALU scan); it is not what bench.py measures for the fp32
                           * configurations. */
     NNS_REFS_SOA = 64    /* the reference points are given dimension-major, r[t * n + j] (a dense [k][n]
@@ -176,8 +177,8 @@ int nns_index_search(nns_index *ix, int m, const float *q_dev,
 /* bf16 points (config C5: bf16 inputs, fp32 accumulate).  Arrays hold raw bf16 bit
  * patterns (uint16_t), same [points][k] layout.  Semantics: V0's arithmetic on the
  * bf16 values widened to fp32 (the reference has no bf16 code; SURVEY 8c defines the
- * oracle this way).  MFMA filter for 32 <= k <= 256 (v_mfma_f32_32x32x16_bf16), exact
- * kernels otherwise.  An index and its queries must have the same dtype. */
+ * oracle this way).  MFMA filter for 32 <= k <= 1024 (v_mfma_f32_16x16x32_bf16 up to 256,
+ * v_mfma_f32_32x32x16_bf16 beyond), exact kernels otherwise.  An index and its queries must have the same dtype. */
 int nns_index_create_bf16(nns_index **out, int device, int k, int n,
                           const uint16_t *r_dev, int64_t index_base,
                           unsigned flags, void *stream);

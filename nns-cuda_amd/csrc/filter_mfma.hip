@@ -259,15 +259,15 @@ using OpBF16K128 = OpBF16T<8>;    // KT = 128: k <= 128 without padding to 256 (
 
 // OpBF16T32: v_mfma_f32_32x32x16_bf16 (the first version; kept for A/B builds with
 // -DNNS_BF16_TILE32): 16 bytes = 8 bf16 = one operand, lane = query, 16 refs per lane.
-template <int SPB_, int QB_>
+template <int SPB_, int QB_, int NW_ = NNS_F_NW_BF16>
 struct OpBF16T32T {
     static constexpr int kSPB = SPB_;         // fragment steps (16 dims each) per 32-ref block
     static constexpr bool kTile16 = false;
-    static constexpr bool kLag = true;
+    static constexpr bool kLag = NW_ == 8;    // (one wave per SIMD has no partner to stagger against)
     static constexpr bool kTauInRegs = true;
     using Acc = AccSet;
     static constexpr int kQB = QB_;
-    static constexpr int kNW = NNS_F_NW_BF16;
+    static constexpr int kNW = NW_;
     static constexpr int kPrefetch = NNS_F_PF_BF16;   // one MFMA (32 cycles) per fragment and query block
     __device__ static __forceinline__ f32x16 mma(const float4 &a, const float4 &b, f32x16 acc)
     {
@@ -279,6 +279,12 @@ using OpBF16T32 = OpBF16T32T<16, NNS_F_QB_BF16>;   // KT = 256
 // KT = 512 (256 < k <= 512): the 32x32x16 form with ONE query block per wave (its resident operands are
 // 128 registers) and one 32-ref block per ring slot — the bf16 twin of OpF32K256
 using OpBF16K512 = OpBF16T32T<32, 1>;
+// KT = 1024 (512 < k <= 1024): K-split accumulation.  The resident operands of one query block are 256
+// registers, so a workgroup is FOUR waves (one per SIMD, up to 512 registers each) = 128 queries; a 32-ref
+// block is 64 fragment steps = TWO ring slots, and its accumulators carry across the slot barrier: seeded at
+// step 0 of the even slot, retired at step 31 of the odd one.  One MFMA per 1 KiB LDS fragment, like the
+// 512-deep tile: LDS-bandwidth bound (~50 % of the bf16 MFMA peak), still ~50x the exact VALU scan.
+using OpBF16K1024 = OpBF16T32T<64, 1, 4>;
 #if NNS_BF16_TILE16
 using OpBF16Active = OpBF16;
 #else
@@ -333,11 +339,13 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
 {
     constexpr int F_NW = OP::kNW;
     constexpr int SPB = OP::kSPB;                      // fragment steps per image block
-    constexpr int BPS = 32 / SPB;                      // image blocks per ring slot (2 or 8)
+    constexpr int SPBLK = SPB > 32 ? SPB / 32 : 1;     // ring slots per image block (2 at the 1024-deep tile)
+    constexpr int BPS = SPB > 32 ? 1 : 32 / SPB;       // image blocks per ring slot (a deep block: its slot's share)
     constexpr int BLK_BYTES = SPB * 1024;
-    constexpr int SLOT_REFS = 32 * BPS;
+    constexpr int SLOT_REFS = 32 * BPS;                // norms DMAed with a slot
     constexpr int F_PPW = F_SLOT_COORD / 1024 / F_NW;   // 1 KiB DMA pieces per wave per slot
-    static_assert(32 % SPB == 0 && SPB >= 2, "a slot is 32 fragment steps");
+    static_assert((32 % SPB == 0 && SPB >= 2) || SPB == 64, "a slot is 32 fragment steps");
+    static_assert(SPBLK == 1 || (!OP::kLag && !OP::kTile16), "blocks spanning two slots: lock-step 32x32 tiles only");
     static_assert(SLOT_REFS == 32 || SLOT_REFS == 64 || SLOT_REFS == 128 || SLOT_REFS == 256 || SLOT_REFS == 512,
                   "norm pieces: one dword per lane, or dwordx4 pieces of 256 norms");
     constexpr int F_NP = SLOT_REFS <= 256 ? 1 : SLOT_REFS / 256;   // norm DMA pieces per slot
@@ -415,7 +423,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         } else if constexpr (SLOT_REFS <= 64) {   // (128- and 256-ref slots: one dwordx4 piece of 256 norms)
             // the slot's norms: every wave copies the same bytes to the same words (keeps each
             // wave's DMA count per slot identical; a 32-ref slot also copies the next slot's 32)
-            dma4(a.rnorm + gslot * SLOT_REFS + lane, dst + F_SLOT_COORD);
+            dma4(a.rnorm + (gslot / SPBLK) * SLOT_REFS + lane, dst + F_SLOT_COORD);   // (a deep block: both its slots)
         } else {
             const int np = p - F_PPW;             // 256 norms per piece
             dma16(a.rnorm + gslot * SLOT_REFS + np * 256 + lane * 4, dst + F_SLOT_COORD + np * 1024);
@@ -744,11 +752,12 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     using I0c = std::integral_constant<int, 0>;
     using I1c = std::integral_constant<int, 1>;
     // s: slot index relative to slot0; cur/prev/nxt: ring images of slots s, s-1, s+1
-    auto interval = [&](auto lag_c, auto dph_c, int s, const char *cur, const char *prev, const char *nxt) __attribute__((always_inline)) {
+    auto interval = [&](auto lag_c, auto dph_c, auto half_c, int s, const char *cur, const char *prev, const char *nxt) __attribute__((always_inline)) {
         constexpr int LAG = decltype(lag_c)::value;
         constexpr int DPH = decltype(dph_c)::value;   // DMA phase: the SIMD partners issue at different steps
+        constexpr int HALF = decltype(half_c)::value; // blocks spanning two slots: which of them this interval is
         const bool first = s == 0;
-        const int blk0_global = (slot0 + s) * BPS;
+        const int blk0_global = SPBLK == 1 ? (slot0 + s) * BPS : (slot0 + s) / SPBLK;
         // compile-time schedule: step t works on position u = t - LAG * LAGOFF of the slot's
         // fragment stream (u < 0: tail of the previous slot; u >= 32: head of the next one)
         auto load = [&](auto tc_) __attribute__((always_inline)) {
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             constexpr int t = decltype(tc_)::value;
             constexpr int u = t - LAG * LAGOFF;
             constexpr int blk = u < 0 ? BPS - 1 : u / SPB;
-            constexpr int b = u < 0 ? SPB + u : u % SPB;
+            constexpr int b = (u < 0 ? SPB + u : u % SPB) + 32 * HALF;   // operand / k position inside the block
             load(std::integral_constant<int, t + PF>{});
             // one DMA piece per step, two slots ahead, in the MFMA shadow, at different steps
             // for the two SIMD partners (an LDS-DMA issue stalls the issuing wave ~100 cycles;
@@ -844,24 +853,37 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // tuples at the merge and at the loop header and reconciles them with ~48 v_mov at every back-edge.
     // Every wave executes exactly ns barriers whichever copy it runs.
     auto slot_loop = [&](auto lag_c, auto dph_c) __attribute__((always_inline)) {
-        for (int s = 0; s < ns; ++s) {
+        auto sync_slot = [&]() __attribute__((always_inline)) {
             if constexpr ((kAblate & 1) == 0) {
                 // my share of slot s+1 has landed (issued an interval ago; the only DMA in flight)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 // everyone's share of slot s+1 has landed; everyone is done with slot s-2
                 __builtin_amdgcn_s_barrier();
             }
-            interval(lag_c, dph_c, s, ring(s), ring(s - 1), ring(s + 1));
-            if constexpr (!OP::kLag) {
-                // lock-step partners (staggering only their DMA issue steps, or packing / spreading the
-                // pieces differently, measured +-0.5 % on C5).  The interval ends on the MFMAs that finish
-                // ref tile 1, which is retired in the NEXT interval: hipcc is free to split / copy those
-                // accumulators at the loop back-edge (it did: v_mov of single elements right behind the
-                // MFMAs = stale reads).  Whatever it does with them now happens behind the 8 wait states
-                // their readers need.
+        };
+        if constexpr (SPBLK == 2) {
+            // a block = two slots (ns is even: filter_plan): even slot = k-steps 0..31, odd slot = 32..63
+            for (int s = 0; s < ns; s += 2) {
+                sync_slot();
+                interval(lag_c, dph_c, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
+                sync_slot();
+                interval(lag_c, dph_c, I1{}, s + 1, ring(s + 1), ring(s), ring(s + 2));
+            }
+        } else {
+            for (int s = 0; s < ns; ++s) {
+                sync_slot();
+                interval(lag_c, dph_c, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
+                if constexpr (!OP::kLag) {
+                    // lock-step partners (staggering only their DMA issue steps, or packing / spreading the
+                    // pieces differently, measured +-0.5 % on C5).  The interval ends on the MFMAs that finish
+                    // ref tile 1, which is retired in the NEXT interval: hipcc is free to split / copy those
+                    // accumulators at the loop back-edge (it did: v_mov of single elements right behind the
+                    // MFMAs = stale reads).  Whatever it does with them now happens behind the 8 wait states
+                    // their readers need.
 #ifndef NNS_F_NOLATCHFENCE   // (timing experiments only: without it the results are wrong)
-                if constexpr (T16) OP::mma16_tail_fence(acc);
+                    if constexpr (T16) OP::mma16_tail_fence(acc);
 #endif
+                }
             }
         }
     };
@@ -986,6 +1008,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
         if (k <= 128) kt = 128;        // OpBF16K128: 4 k-steps per 16-ref tile, 4 blocks per slot
         else if (k <= 256) kt = 256;
         else if (k <= 512) kt = 512;   // OpBF16K512
+        else if (k <= 1024) kt = 1024; // OpBF16K1024: K-split accumulation over two ring slots per block
     } else {
         if (k <= 16) kt = 16;          // OpF32K16: 2 fragment steps per block, 16 blocks per slot
         else if (k <= 32) kt = 32;     // OpF32K32: 4 fragment steps per block, 8 blocks per slot
@@ -994,20 +1017,25 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
         else if (k <= 256) kt = 256;   // OpF32K256: 32 fragment steps per block, 1 block per slot
     }
     if (!kt) {
-        set_error("MFMA filter: k = %d exceeds the deepest tile (fp32 operands: 256, bf16 operands: 512)", k);
+        set_error("MFMA filter: k = %d exceeds the deepest tile (fp32 operands: 256, bf16 operands: 1024)", k);
         return NNS_ERR_UNSUPPORTED;
     }
     g->bf16 = bf16 ? 1 : 0;
     g->mixed = mixed ? 1 : 0;
     g->kt = kt;
-    g->lpq = (bf16 && kt != 512 && OpBF16Active::kTile16) ? 4 : 2;
+    g->lpq = (bf16 && kt <= 256 && OpBF16Active::kTile16) ? 4 : 2;
     // queries per workgroup
-    const int qw = 32 * (bf16 ? (kt == 512 ? OpBF16K512::kQB * OpBF16K512::kNW : OpBF16Active::kQB * OpBF16Active::kNW)
+    const int qw = 32 * (bf16 ? (kt == 1024  ? OpBF16K1024::kQB * OpBF16K1024::kNW
+                              : kt == 512 ? OpBF16K512::kQB * OpBF16K512::kNW
+                                          : OpBF16Active::kQB * OpBF16Active::kNW)
                               : (kt == 256 ? OpF32K256::kQB * OpF32K256::kNW : OpF32::kQB * OpF32::kNW));
     g->m_pad = divup(m, qw) * qw;
     // refs per ring slot (32 fragment steps of 8 fp32 / 16 bf16 dims)
-    const int slot_pts = bf16 ? 32 * (32 / (kt / 16)) : 32 * (32 / (kt / 8));
-    g->n_pad = divup(n, slot_pts) * slot_pts;
+    const int steps_per_block = bf16 ? kt / 16 : kt / 8;
+    const int slot_pts = steps_per_block <= 32 ? 32 * (32 / steps_per_block) : 32 / (steps_per_block / 32);
+    const int slots_per_block = steps_per_block <= 32 ? 1 : steps_per_block / 32;
+    const int pad_pts = slot_pts * slots_per_block;   // whole blocks
+    g->n_pad = divup(n, pad_pts) * pad_pts;
     g->total_slots = g->n_pad / slot_pts;
     g->qgroups = g->m_pad / qw;
     // One 8-wave workgroup is resident per CU (132 KiB of LDS), so the grid runs in rounds of
@@ -1034,7 +1062,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
     }
     if (splits > g->total_slots) splits = g->total_slots;
     if (splits > 65535) splits = 65535;
-    g->slots_per_split = divup(g->total_slots, splits);
+    g->slots_per_split = divup(divup(g->total_slots, splits), slots_per_block) * slots_per_block;   // whole blocks
     g->splits = divup(g->total_slots, g->slots_per_split);
     g->slot_pts = slot_pts;
     return NNS_OK;
@@ -1091,8 +1119,9 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
         NNS_HIP(hipMemsetAsync(a.stamps, 0, (nwg * 4 + 8) * sizeof(unsigned long long), st));
     }
 #endif
-    const int rc = g.bf16 ? (g.kt == 128   ? launch_filter_t<OpBF16K128>(g, a, st)
-                             : g.kt == 512 ? launch_filter_t<OpBF16K512>(g, a, st)
+    const int rc = g.bf16 ? (g.kt == 128    ? launch_filter_t<OpBF16K128>(g, a, st)
+                             : g.kt == 512  ? launch_filter_t<OpBF16K512>(g, a, st)
+                             : g.kt == 1024 ? launch_filter_t<OpBF16K1024>(g, a, st)
                                            : launch_filter_t<OpBF16Active>(g, a, st))
                           : (g.kt == 16    ? launch_filter_t<OpF32K16>(g, a, st)
                              : g.kt == 32  ? launch_filter_t<OpF32K32>(g, a, st)

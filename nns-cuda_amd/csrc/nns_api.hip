@@ -50,7 +50,7 @@ static const unsigned kCreateNoSync = 1u << 30;
 static const int64_t kSmallPairs = (int64_t)1 << 24;
 static bool small_exact(int k, int64_t m, int64_t n) { return (k == 8 || k == 16) && m >= kTinyM && m * n <= kSmallPairs; }
 // deepest dimensionality the MFMA filter tiles (bf16 operands; fp32 operands: 256)
-static const int kMaxFilterK = 512;
+static const int kMaxFilterK = 1024;
 
 enum { EV_BEGIN = 0, EV_QPREP, EV_FILTER, EV_FINAL, EV_RERANK, EV_END, EV_R0, EV_R1, EV_COUNT };
 static const int kEvRing = 32;
@@ -126,7 +126,7 @@ static int prep_refs(nns_index *ix, hipStream_t st)
     const FilterGeom &g = ix->geom;
     NNS_HIP(hipMemsetAsync(ix->scal, 0, sizeof(DevScalars), st));
     if (ix->bf16) {
-        NNS_TRY(launch_prep_image_bf16((NNS_BF16_TILE16 && g.kt != 512) ? 1 : 0, g.kt, ix->k, ix->n, g.n_pad, (const uint16_t *)ix->r_dev, -2.0f, INFINITY,
+        NNS_TRY(launch_prep_image_bf16((NNS_BF16_TILE16 && g.kt < 512) ? 1 : 0, g.kt, ix->k, ix->n, g.n_pad, (const uint16_t *)ix->r_dev, -2.0f, INFINITY,
                                        ix->rimg, ix->rnorm, &ix->scal->ymax2_bits,
                                        &ix->scal->r_maxabs_bits, st));
         return NNS_OK;
@@ -466,7 +466,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
                   "per-search scalars must be adjacent");
     NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned) + 2 * sizeof(int), st));
     if (bf16)
-        NNS_TRY(launch_prep_image_bf16((NNS_BF16_TILE16 && g.kt != 512) ? 1 : 0, g.kt, ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
+        NNS_TRY(launch_prep_image_bf16((NNS_BF16_TILE16 && g.kt < 512) ? 1 : 0, g.kt, ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
                                        nullptr, &ix->scal->q_maxabs_bits, st));
     else
         NNS_TRY(launch_prep_image(ix->k, g.kt, m, g.m_pad, (const float *)q_dev, ix->mean, 1.0f, 0.0f,
@@ -988,12 +988,12 @@ int nns_search_bf16_ex(int k, int m, int n, const uint16_t *s_points, const uint
 int nns_warmup(int device)
 {
     NNS_TRY(ensure_device_ok(device));
-    // (k, m, n, bf16): K1a, K1b, the fp32 tile depths 16 / 32 / 64 / 128 / 256, the bf16-operand tile for fp32
-    // points (512), the bf16 tiles 128 / 256 / 512
+    // (k, m, n, bf16): K1a, K1b, the fp32 tile depths 16 / 32 / 64 / 128 / 256, the bf16-operand tiles for fp32
+    // points (512 / 1024), the bf16 tiles 128 / 256 / 512 / 1024
     static const int shapes[][4] = {{3, 64, 512, 0},   {16, 1, 512, 0},   {16, 64, 512, 0},  {24, 64, 512, 0}, {40, 64, 512, 0},
-                                    {100, 64, 512, 0}, {200, 64, 512, 0}, {300, 64, 512, 0}, {64, 64, 512, 1},
-                                    {200, 64, 512, 1}, {300, 64, 512, 1}};
-    const int kmax = 300, mmax = 64, nmax = 512;
+                                    {100, 64, 512, 0}, {200, 64, 512, 0}, {300, 64, 512, 0}, {600, 64, 512, 0}, {64, 64, 512, 1},
+                                    {200, 64, 512, 1}, {300, 64, 512, 1}, {600, 64, 512, 1}};
+    const int kmax = 600, mmax = 64, nmax = 512;
     float *q = (float *)malloc(sizeof(float) * kmax * mmax), *r = (float *)malloc(sizeof(float) * kmax * nmax);
     int *idx = (int *)malloc(sizeof(int) * mmax);
     if (!q || !r || !idx) {

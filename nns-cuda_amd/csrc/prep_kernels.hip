@@ -343,17 +343,99 @@ __global__ __launch_bounds__(256) void image_mixed512_kernel(int k, int npts, co
     if ((tid & 63) == 0 && maxabs_bits) max_word(maxabs_bits, mx);
 }
 
+// KT = 1024 (512 < k <= 1024), operands of v_mfma_f32_32x32x16_bf16 (order 0), for BOTH point types: a
+// 32-point block is 64 KiB of bf16 — more than one staging tile — so the block is produced in two halves of
+// 512 dims through the same LDS tile; the squared norm accumulates in a register across the halves (fp64,
+// fixed order).  T = float: centred by the mean, ONE rounding to bf16 (NNS_FILTER_BF16 / AUTO for fp32 points
+// beyond the fp32 tiles); T = uint16_t: bf16 bit patterns, no centring (a centred bf16 value would need a
+// second rounding).  Same values as image_mixed512_kernel / image_bf16_kernel would produce at their depths.
+template <int KT, typename T>
+__global__ __launch_bounds__(256) void image_deep_kernel(int k, int npts, const T *__restrict__ pts,
+                                                         const float *__restrict__ mean, float scale, float pad_norm,
+                                                         uint16_t *__restrict__ img, float *__restrict__ norms,
+                                                         unsigned *__restrict__ max_norm_bits,
+                                                         unsigned *__restrict__ maxabs_bits)
+{
+    static_assert(KT % 512 == 0, "halves of 512 dims");
+    constexpr int HD = 512, LD = HD + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t tile[32 * LD];
+    __shared__ double nrm[32][8];
+    const int tid = threadIdx.x;
+    const int blk = blockIdx.x;
+    const int p0 = blk * 32;
+    const int i = tid >> 3, part = tid & 7;   // 8 threads per point, 64 consecutive dims each per half
+    const bool live = p0 + i < npts;
+    const T *row = pts + (size_t)(p0 + i) * k;
+    unsigned mx = 0;
+    double acc = 0.0;
+    uint4 *out = reinterpret_cast<uint4 *>(img + (size_t)blk * 32 * KT);
+    for (int half = 0; half < KT / HD; ++half) {
+        for (int tt = part * 64; tt < part * 64 + 64; ++tt) {
+            const int t = half * HD + tt;
+            float c = 0.0f;
+            if (live && t < k) {
+                float v;
+                if constexpr (sizeof(T) == 4) v = (float)row[t];
+                else v = __uint_as_float((unsigned)row[t] << 16);
+                const unsigned b = __float_as_uint(v) & 0x7FFFFFFFu;
+                mx = b > mx ? b : mx;
+                if constexpr (sizeof(T) == 4) c = __fsub_rn(v, mean[t]);   // ONE rounding: x' = fl(x - c)
+                else c = v;
+            }
+            acc += (double)c * (double)c;
+            // scale (+1 / -2) is exact; fp32 points: ONE rounding to bf16 (RNE), NaN stays NaN; bf16 points: exact
+            tile[i * LD + tt] = __builtin_bit_cast(unsigned short, (__bf16)(c * scale));
+        }
+        __syncthreads();
+        // 16-byte fragments of the 32x32x16 operand order: fragment s (16 dims), lane = 32 h + i
+        for (int f = tid; f < (HD / 16) * 64; f += 256) {
+            const int s16 = f >> 6, lane = f & 63;
+            out[(half * (HD / 16) + s16) * 64 + lane] =
+                *reinterpret_cast<const uint4 *>(&tile[(lane & 31) * LD + 16 * s16 + 8 * (lane >> 5)]);
+        }
+        __syncthreads();
+    }
+    nrm[i][part] = acc;
+    __syncthreads();
+    if (tid < 32) {
+        double a2 = 0.0;
+        for (int p = 0; p < 8; ++p) a2 += nrm[tid][p];   // fixed order
+        float nv = (float)a2;
+        unsigned nb = 0;
+        if (p0 + tid >= npts) nv = pad_norm;             // padding never wins (refs: +INF)
+        else nb = __float_as_uint(nv);
+        norms[p0 + tid] = nv;
+        if (max_norm_bits) {
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {
+                const unsigned o = __shfl_xor(nb, off, 64);
+                nb = o > nb ? o : nb;
+            }
+            if (tid == 0) max_word(max_norm_bits, nb);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    if ((tid & 63) == 0 && maxabs_bits) max_word(maxabs_bits, mx);
+}
+
 int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, const float *mean,
                       float scale, float pad_norm, float *img, float *norms,
                       unsigned *max_norm_bits, unsigned *maxabs_bits, hipStream_t st, bool out_bf16)
 {
     const int blocks = npts_pad / 32;
     if (out_bf16) {
-        if (kt != 512 && kt != 256 && kt != 128) {
-            set_error("prep: the bf16 operand image is 128, 256 or 512 deep (kt = %d)", kt);
+        if (kt != 1024 && kt != 512 && kt != 256 && kt != 128) {
+            set_error("prep: the bf16 operand image is 128, 256, 512 or 1024 deep (kt = %d)", kt);
             return NNS_ERR_UNSUPPORTED;
         }
-        if (kt == 512)
+        if (kt == 1024)
+            hipLaunchKernelGGL((image_deep_kernel<1024, float>), dim3(blocks), dim3(256), 0, st, k, npts, pts, mean, scale,
+                               pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
+        else if (kt == 512)
             hipLaunchKernelGGL(image_mixed512_kernel, dim3(blocks), dim3(256), 0, st, k, npts, pts, mean, scale,
                                pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
         else if (kt == 256)
@@ -514,6 +596,9 @@ int launch_prep_image_bf16(int order, int kt, int k, int npts, int npts_pad, con
     else if (kt == 512 && order == 0)
         hipLaunchKernelGGL(image_bf16_kernel<512>, dim3(npts_pad / 32), dim3(256), 0, st, order, k, npts, pts, scale,
                            pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
+    else if (kt == 1024 && order == 0)
+        hipLaunchKernelGGL((image_deep_kernel<1024, uint16_t>), dim3(npts_pad / 32), dim3(256), 0, st, k, npts, pts,
+                           (const float *)nullptr, scale, pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
     else if (kt == 128 && order == 1)
         hipLaunchKernelGGL(image_bf16_kernel<128>, dim3(npts_pad / 32), dim3(256), 0, st, order, k, npts, pts, scale,
                            pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);

@@ -82,10 +82,10 @@ def _bf16_model_cases(rng, kt):
 
 
 @pytest.mark.parametrize("shape", [2, 1])
-@pytest.mark.parametrize("kt", [128, 256, 512])
+@pytest.mark.parametrize("kt", [128, 256, 512, 1024])
 def test_bf16_mfma_error_model(pkg, orc, shape, kt):
     """The bf16 MFMA's accumulation (fp32 accumulate, order and rounding undocumented) against fp64 on
-    bf16-representable operands, at EVERY depth the product runs bf16 tiles (128 / 256 / 512), for both
+    bf16-representable operands, at EVERY depth the product runs bf16 tiles (128 / 256 / 512 / 1024), for both
     MFMA shapes (2 = v_mfma_f32_16x16x32_bf16 with the operand / result lane mapping K2's images and the
     filter's epilogue assume — a wrong mapping shows up as O(1) errors here; 1 = 32x32x16), several seeds
     and adversarial magnitudes.  The proof margin tau assumes 2u per add (nns_internal.h tau_consts,
@@ -117,7 +117,7 @@ def test_bf16_mfma_error_model(pkg, orc, shape, kt):
     print(f"bf16 MFMA shape {shape} kt {kt}: worst error / e3 bound = {worst:.4f}")
 
 
-@pytest.mark.parametrize("kt", [128, 256, 512])
+@pytest.mark.parametrize("kt", [128, 256, 512, 1024])
 def test_bf16_operand_rounding_model_mode2(pkg, orc, kt):
     """tau mode 2 (fp32 points, operands rounded to bf16, NNS_FILTER_BF16): the filter's score error
     against the UNROUNDED fp32 values — rounding bound 2^-6 (1 + 2^-8) |x'||y'| plus the accumulate
@@ -136,7 +136,7 @@ def test_bf16_operand_rounding_model_mode2(pkg, orc, kt):
             a_true = (-2.0 * y).astype(np.float32)                      # exact scaling
             a, b = orc.round_bf16(a_true), orc.round_bf16(x)            # what K2 writes (RNE)
             c0 = (y.astype(np.float64) ** 2).sum(1).astype(np.float32)
-            out = pkg.selftest_mfma(a, b, c0, bf16=2 if kt != 512 else 1)
+            out = pkg.selftest_mfma(a, b, c0, bf16=2 if kt < 512 else 1)
             exact = c0.astype(np.float64)[:, None] + a_true.astype(np.float64) @ x.astype(np.float64).T
             err = np.abs(out.astype(np.float64) - exact)
             y2max = float((y.astype(np.float64) ** 2).sum(1).max())
@@ -383,7 +383,7 @@ def _check_bf16(pkg, orc, q, r, paths=("auto",), shards=(1,)):
     with np.errstate(all="ignore"):
         want_idx, want_dist = orc.v0_search(qw, rw, threads=8)
     for path in paths:
-        if path == "mfma" and q.shape[1] > 512:
+        if path == "mfma" and q.shape[1] > 1024:
             continue
         for s in shards:
             idx, dist = pkg.search_bf16(qb, rb, return_distances=True, shards=s, path=path)
@@ -1108,3 +1108,40 @@ def test_whole_call_pipelined_upload(pkg, orc):
     assert np.array_equal(pkg.search(q, r2), w2)
     pkg.shutdown()                       # releases the pinned ring; the next call rebuilds it
     assert np.array_equal(pkg.search(q, r), want_idx)
+
+
+@pytest.mark.parametrize("shape", [(300, 5000, 1024), (700, 20001, 600), (130, 3000, 800), (1100, 9000, 513)])
+def test_k1024_tile_shapes(pkg, orc, shape):
+    """512 < k <= 1024: K-split accumulation on the MFMA path — the 1024-deep bf16 tile (one query block per
+    wave on one wave per SIMD, a 32-ref block spanning TWO ring slots with its accumulators carried across
+    the slot barrier).  bf16 points (forced and AUTO) and fp32 points (AUTO takes the bf16-operand filter with
+    the rounding-widened margin + exact fp32 re-rank): V0's bits, whole and sharded, exact duplicates and
+    near-duplicates below bf16 resolution included; and faster than the exact VALU scan."""
+    m, n, k = shape
+    rng = np.random.default_rng(10240 + k)
+    q = rng.random((m, k), dtype=np.float32)
+    r = rng.random((n, k), dtype=np.float32)
+    r[n // 2:n // 2 + 30] = r[:30]                                   # exact duplicates: lowest index
+    tw = r[60:90].copy()
+    tw[:, 5] += np.float32(3e-4)                                     # below bf16 resolution
+    r[n // 3:n // 3 + 30] = tw
+    q[:25] = r[60:85] + rng.normal(0, 1e-4, (25, k)).astype(np.float32)
+    _check_bf16(pkg, orc, q, r, paths=("mfma", "auto"), shards=(1, 3))
+    want_idx, want_dist = orc.v0_search(q, r, threads=8)
+    for kw in ({"path": "auto"}, {"path": "mfma", "filter_bf16": True}):
+        for shards in (1, 3):
+            idx, dist = pkg.search(q, r, return_distances=True, shards=shards, **kw)
+            assert np.array_equal(idx, want_idx), (kw, shards)
+            assert np.array_equal(_bits(dist), _bits(want_dist))
+    for bf in (False, True):
+        rr = torch.from_numpy(orc.round_bf16(r) if bf else r).cuda()
+        qq = torch.from_numpy(orc.round_bf16(q) if bf else q).cuda()
+        if bf:
+            rr, qq = rr.to(torch.bfloat16), qq.to(torch.bfloat16)
+        ix = pkg.Index(rr, profile=True)
+        ix.search(qq)
+        st = ix.stats()
+        assert st["path"] == 2 and st["k_tile"] == 1024, st
+        ix.close()
+    with pytest.raises(pkg.NNSError):
+        pkg.search(np.zeros((4, 1025), np.float32), np.zeros((9, 1025), np.float32), path="mfma", filter_bf16=True)

@@ -8,8 +8,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
 pkg = graft.load_package()
 m, n = 65536, 1048576
-CASES = [(16, "f32"), (32, "f32"), (64, "f32"), (128, "f32"), (256, "f32"), (512, "f32"),
-         (128, "bf16"), (256, "bf16"), (512, "bf16")]
+CASES = [(16, "f32"), (32, "f32"), (64, "f32"), (128, "f32"), (256, "f32"), (512, "f32"), (1024, "f32"),
+         (128, "bf16"), (256, "bf16"), (512, "bf16"), (1024, "bf16")]
+if "--deep" in sys.argv:
+    CASES = [(1024, "f32"), (1024, "bf16"), (600, "bf16")]
 for k, dt in CASES:
     q = torch.empty((m, k), dtype=torch.float32, device="cuda"); r = torch.empty((n, k), dtype=torch.float32, device="cuda")
     pkg.fill_uniform(q, 1000, 0); pkg.fill_uniform(r, 1000, m * k)
@@ -25,4 +27,14 @@ for k, dt in CASES:
     peak = 157.3 if (dt == "f32" and k <= 256) else 2500.0
     print(f"{dt:4s} points k={k:3d}: tile kt={st['k_tile']:3d}  filter {st['filter_ms']:8.2f} ms = {tf:7.1f} TFLOP/s algorithmic = "
           f"{tf / peak * 100:5.1f} % of {peak:.1f}  (total {st['total_ms']:.2f} ms, ambiguous {st['ambiguous']}, near-ties {st['multi_candidate']})", flush=True)
-    ix.close(); del q, r, keys; torch.cuda.empty_cache(); pkg.trim()
+    ix.close()
+    if k > 512 and "--deep" in sys.argv:   # the same through the exact VALU kernels, on 1/16 of the queries
+        ms = m // 16
+        ixe = pkg.Index(r, path="exact", profile=True)
+        ke = torch.empty(ms, dtype=torch.int64, device="cuda")
+        ixe.search_keys(q[:ms], ke); ixe.stats(); ixe.search_keys(q[:ms], ke)
+        ste = ixe.stats()
+        print(f"     exact VALU scan of {ms} queries: {ste['exact_ms']:.1f} ms -> {ste['exact_ms'] * 16:.0f} ms for all {m}; "
+              f"keys equal: {bool(torch.equal(ke, keys[:ms]))}", flush=True)
+        ixe.close()
+    del q, r, keys; torch.cuda.empty_cache(); pkg.trim()
