@@ -710,6 +710,12 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                 if constexpr (ks == 0) OP::mma16_seed(frag, bq[qt][0], acc.template at<rt, qt>(), rt == 0 ? nseed0 : nseed1);
                 else OP::mma16(frag, bq[qt][ks], acc.template at<rt, qt>());
                 if constexpr (ks == 1) {
+                    // Name the retiring tile's accumulator as ONE in/out tuple before its elements are read:
+                    // without it hipcc carries elements 1 and 3 of each tile across the loop back-edge in
+                    // separate registers (8 v_mov at the latch, 8 more to put them back in front of the tile's
+                    // seed MFMA, whose in/out constraint "reads" them): 16 of the 74 VALU instructions of an
+                    // interval, in a loop where every VALU issue cycle is an MFMA issue cycle lost.
+                    asm volatile("" : "+v"(acc.template at<ot, qt>()));
                     const f32x4 o = acc.template at<ot, qt>();
                     if constexpr ((kAblate & 2) != 0) asm volatile("" ::"v"(o));
                     else tmh[qt] = fminf(fminf(fminf(o[0], o[1]), o[2]), o[3]);
