@@ -228,6 +228,11 @@ int nns_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset,
  * fp64).  These are the error models behind the filter's proof margin tau. */
 int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const float *c0,
                       float *out);
+/* Diagnostic: what the filter's slow path does when the lanes that carry one query share their record
+ * thresholds (short ref streams): out64[l] = min of in64 over the lanes l ^ 32 (tile16 = 0: 32x32 MFMA tiles)
+ * or l ^ 16, l ^ 32, l ^ 48 (tile16 = 1: 16x16 tiles) — through the very row-swap instructions the kernel
+ * uses.  HOST buffers of 64 floats.  A wrong lane pairing would hand a query another query's threshold. */
+int nns_selftest_lane_share(int tile16, const float *in64, float *out64);
 /* Diagnostic (host only): the constants of the proof margin tau(a) = c0 + c1 * max(a + x2, 0) the
  * filter and K5 use for a query of squared norm qnorm2 against refs of maximum squared norm ymax2 at
  * tile depth kt; mode 0 fp32 operands, 1 bf16 points, 2 fp32 points rounded to bf16 operands.

@@ -318,6 +318,25 @@ __device__ __forceinline__ void dma4(const void *g, unsigned lds_byte)
                  : "memory");
 }
 
+// min over the lanes that carry the same query: l ^ 32 (32x32 tiles), and l ^ 16 too (16x16 tiles).  Row
+// swaps (v_permlane32_swap / v_permlane16_swap, gfx950), not ds_bpermute: no LDS round trip on the slow
+// path.  swap(t, t) returns {old t with its upper rows replaced by the partner's, and vice versa}: the min of
+// the two halves of the pair is min(t[l], t[l ^ 32]) on every lane (checked on hardware:
+// nns_selftest_lane_share).
+template <bool T16>
+__device__ __forceinline__ float share_min(float t)
+{
+    const unsigned tb = __float_as_uint(t);
+    const auto s32 = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);
+    t = fminf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));          // min(t[l], t[l ^ 32])
+    if constexpr (T16) {
+        const unsigned tb2 = __float_as_uint(t);
+        const auto s16 = __builtin_amdgcn_permlane16_swap(tb2, tb2, false, false);
+        t = fminf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));      // min(t[l], t[l ^ 16])
+    }
+    return t;
+}
+
 struct FilterArgs {
     const float4 *qimg;     // [m_pad/32][16][64] 16-byte fragments
     const char *rimg;       // [n_pad/32][16 KiB]
@@ -520,16 +539,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         // every tile is slow), costs 0.2 % on C3 / C5: a launch-time choice by stream length
         // (launch_filter).  Row swaps (v_permlane32_swap / 16_swap, gfx950), not ds_bpermute: no LDS
         // round trip.  (Wave-uniform slow path: every lane is active here.)
-        if (a.share_thr) {
-            const unsigned tb = __float_as_uint(t);
-            const auto s32 = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);
-            t = fminf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));          // min(t[l], t[l ^ 32])
-            if constexpr (T16) {
-                const unsigned tb2 = __float_as_uint(t);
-                const auto s16 = __builtin_amdgcn_permlane16_swap(tb2, tb2, false, false);
-                t = fminf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));      // min(t[l], t[l ^ 16])
-            }
-        }
+        if (a.share_thr) t = share_min<T16>(t);
         // (a finite threshold: "x <= thr" then also excludes the +INF scores of padding refs)
         thr[st] = fminf(t, 3.4028234663852886e38f);
     };
@@ -992,6 +1002,20 @@ __global__ __launch_bounds__(64) void mfma_selftest_kernel(int kt, int bf16, con
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i] = acc[r];
+}
+
+// self-test of share_min: out[l] = the value lane l would adopt from in[0..63]
+__global__ __launch_bounds__(64) void lane_share_selftest_kernel(int t16, const float *__restrict__ in, float *__restrict__ out)
+{
+    const float t = in[threadIdx.x];
+    out[threadIdx.x] = t16 ? share_min<true>(t) : share_min<false>(t);
+}
+
+int launch_lane_share_selftest(int t16, const float *in, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(lane_share_selftest_kernel, dim3(1), dim3(64), 0, st, t16, in, out);
+    NNS_HIP(hipGetLastError());
+    return NNS_OK;
 }
 
 int launch_mfma_selftest(int kt, int bf16, const float *a, const float *b, const float *c0, float *out,

@@ -874,6 +874,21 @@ static int search_host_pipelined(int k, int m, int n, const void *s_points, cons
     return rc;
 }
 
+int nns_selftest_lane_share(int tile16, const float *in64, float *out64)
+{
+    if (!in64 || !out64) return NNS_ERR_INVALID;
+    NNS_TRY(ensure_device_ok(0));
+    float *d = nullptr;
+    NNS_HIP(pool_alloc(&d, 128 * sizeof(float)));
+    int rc = NNS_OK;
+    if (hipMemcpy(d, in64, 64 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = NNS_ERR_HIP;
+    if (rc == NNS_OK) rc = launch_lane_share_selftest(tile16 ? 1 : 0, d, d + 64, nullptr);
+    if (rc == NNS_OK && hipMemcpy(out64, d + 64, 64 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = NNS_ERR_HIP;
+    if (rc == NNS_ERR_HIP) set_error("nns_selftest_lane_share: %s", hipGetErrorString(hipGetLastError()));
+    pool_free(d);
+    return rc;
+}
+
 static int search_host_impl(int k, int m, int n, const void *s_points, const void *r_points, int bf16,
                             int *idx_out, float *dist_out, int num_shards, unsigned flags, int device)
 {

@@ -230,6 +230,7 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
                   hipStream_t st);
 int launch_mfma_selftest(int kt, int bf16, const float *a, const float *b, const float *c0, float *out,
                          hipStream_t st);
+int launch_lane_share_selftest(int t16, const float *in, float *out, hipStream_t st);
 
 // finalize.hip (K5)
 int launch_finalize(const FilterGeom &g, int k, int m, int n, const void *q, const void *r,

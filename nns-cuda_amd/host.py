@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "nns_last_error", "nns_version", "nns_selftest_mfma",
     "nns_index_create_bf16", "nns_index_search_bf16", "nns_search_bf16_ex", "nns_search_f32_multi",
     "nns_trim", "nns_warmup", "nns_shutdown", "nns_search_bf16_multi",
-    "nns_index_near_ties", "nns_tau_consts", "nns_index_search_indices",
+    "nns_index_near_ties", "nns_tau_consts", "nns_index_search_indices", "nns_selftest_lane_share",
     "nns_comm_unique_id", "nns_comm_create", "nns_comm_size", "nns_comm_allreduce_min", "nns_comm_destroy",
 )
 NNS_COMM_ID_BYTES = 128
@@ -103,6 +103,7 @@ def _load() -> ctypes.CDLL:
     lib.nns_index_search_indices.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
     lib.nns_index_near_ties.argtypes = [c_vp, c_vp, c_int, ctypes.POINTER(c_int)]
     lib.nns_tau_consts.argtypes = [c_int, ctypes.c_float, ctypes.c_float, c_int, c_vp]
+    lib.nns_selftest_lane_share.argtypes = [c_int, c_vp, c_vp]
     lib.nns_keys_min.argtypes = [c_vp, c_vp, c_int, c_vp]
     lib.nns_keys_unpack.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
     lib.nns_fill_uniform.argtypes = [c_vp, c_sz, c_u64, c_u64, c_vp]
@@ -142,6 +143,15 @@ def selftest_mfma(a: np.ndarray, b: np.ndarray, c0: np.ndarray, bf16: bool = Fal
     out = np.empty((32, 32), np.float32)
     _check(lib.nns_selftest_mfma(a.shape[1], int(bf16), a.ctypes.data, b.ctypes.data, c0.ctypes.data, out.ctypes.data),
            "nns_selftest_mfma")
+    return out
+
+
+def selftest_lane_share(values, tile16: bool) -> np.ndarray:
+    """out[l] of nns_selftest_lane_share for 64 lane values."""
+    v = np.ascontiguousarray(values, np.float32)
+    assert v.shape == (64,)
+    out = np.empty(64, np.float32)
+    _check(lib.nns_selftest_lane_share(int(tile16), v.ctypes.data, out.ctypes.data), "nns_selftest_lane_share")
     return out
 
 

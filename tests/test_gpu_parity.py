@@ -1145,3 +1145,17 @@ def test_k1024_tile_shapes(pkg, orc, shape):
         ix.close()
     with pytest.raises(pkg.NNSError):
         pkg.search(np.zeros((4, 1025), np.float32), np.zeros((9, 1025), np.float32), path="mfma", filter_bf16=True)
+
+
+def test_lane_threshold_sharing_pairs_the_right_lanes(pkg):
+    """The slow path lets the lanes that carry one query adopt the smallest of their thresholds (short ref
+    streams), through v_permlane32_swap / v_permlane16_swap.  A wrong pairing would hand a query another
+    query's threshold (silently dropping candidates): check the instructions' lane pairing on the hardware."""
+    rng = np.random.default_rng(606)
+    for _ in range(5):
+        v = rng.normal(0, 100, 64).astype(np.float32)
+        lanes = np.arange(64)
+        want32 = np.minimum(v, v[lanes ^ 32])
+        want16 = np.minimum(np.minimum(v, v[lanes ^ 16]), np.minimum(v[lanes ^ 32], v[lanes ^ 48]))
+        assert np.array_equal(pkg.selftest_lane_share(v, False), want32)
+        assert np.array_equal(pkg.selftest_lane_share(v, True), want16)
