@@ -147,7 +147,10 @@ __device__ __forceinline__ nns_key wave_min_key(nns_key v)
 #define NNS_K1A_QPL 2
 #endif
 constexpr int K1A_QPL = NNS_K1A_QPL;   // queries per lane
-constexpr int K1A_LDS_FLOATS = 4096;   // 16 KiB ref tile
+#ifndef NNS_K1A_LDS_FLOATS
+#define NNS_K1A_LDS_FLOATS 4096
+#endif
+constexpr int K1A_LDS_FLOATS = NNS_K1A_LDS_FLOATS;   // 16 KiB ref tile
 #ifndef NNS_K1A_WAVES
 #define NNS_K1A_WAVES 8192   // target number of waves in the grid (8 per SIMD)
 #endif
