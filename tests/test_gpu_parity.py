@@ -1159,3 +1159,27 @@ def test_lane_threshold_sharing_pairs_the_right_lanes(pkg):
         want16 = np.minimum(np.minimum(v, v[lanes ^ 16]), np.minimum(v[lanes ^ 32], v[lanes ^ 48]))
         assert np.array_equal(pkg.selftest_lane_share(v, False), want32)
         assert np.array_equal(pkg.selftest_lane_share(v, True), want16)
+
+
+@pytest.mark.timeout(600)
+def test_bench_rccl_path_world_size_one():
+    """bench.py as ONE rank under torch.distributed.run with the real `nccl` (= RCCL) backend: process group,
+    the 128-byte id carried by torch.distributed, the library's own communicator (nns_comm_create), the
+    library-issued ncclAllReduce(uint64, min) inside the timed step, its bit-for-bit cross-check against
+    torch.distributed.all_reduce, teardown, and the JSON line last on stdout (RCCL prints a banner).  The
+    closest rehearsal of the N > 1 exchange a one-GPU box allows."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(root, "bench.py"),
+           "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "c3s", "--verify", "--no-cpu-baseline",
+           "--exchange", "library"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = out.stdout.strip().splitlines()[-1]
+    d = json.loads(last)                                  # the LAST line is the JSON line
+    assert d["n_gpus"] == 1 and d["verified_vs_unsharded"] is True
+    assert d["exchange"]["impl"].startswith("nns_comm_allreduce_min") and d["exchange"]["rccl_ranks"] == 1
+    assert d["exchange"]["matches_torch_all_reduce"] is True
