@@ -228,6 +228,12 @@ int nns_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset,
  * fp64).  These are the error models behind the filter's proof margin tau. */
 int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const float *c0,
                       float *out);
+/* Diagnostic (host only, no device needed): the launch geometry the MFMA filter would use for a k-D search of
+ * m queries over n refs.  out[0..11] = {tile depth kt, bf16 operands, fp32 points rounded to bf16 operands,
+ * candidate lists per query, m_pad, n_pad, ring slots in total, ref-range splits (grid.y), slots per split,
+ * query groups (grid.x), refs per ring slot, queries per workgroup}.  NNS_ERR_UNSUPPORTED beyond the deepest
+ * tile.  Lets CPU tests check the planner's invariants (coverage, padding, whole blocks per split). */
+int nns_plan_filter(int k, int m, int n, int bf16_points, unsigned flags, int *out, int out_len);
 /* Diagnostic: what the filter's slow path does when the lanes that carry one query share their record
  * thresholds (short ref streams): out64[l] = min of in64 over the lanes l ^ 32 (tile16 = 0: 32x32 MFMA tiles)
  * or l ^ 16, l ^ 32, l ^ 48 (tile16 = 1: 16x16 tiles) — through the very row-swap instructions the kernel

@@ -874,6 +874,18 @@ static int search_host_pipelined(int k, int m, int n, const void *s_points, cons
     return rc;
 }
 
+int nns_plan_filter(int k, int m, int n, int bf16_points, unsigned flags, int *out, int out_len)
+{
+    if (!out || out_len < 12 || k <= 0 || m <= 0 || n <= 0) return NNS_ERR_INVALID;
+    const bool mixed = !bf16_points && ((flags & NNS_FILTER_BF16) || (k > 256 && (flags & NNS_PATH_MASK) == NNS_PATH_AUTO));
+    FilterGeom g{};
+    NNS_TRY(filter_plan(k, m, n, bf16_points != 0, &g, mixed));
+    const int v[12] = {g.kt, g.bf16, g.mixed, g.lpq, g.m_pad, g.n_pad, g.total_slots, g.splits, g.slots_per_split,
+                       g.qgroups, g.slot_pts, g.m_pad / g.qgroups};
+    memcpy(out, v, sizeof(v));
+    return NNS_OK;
+}
+
 int nns_selftest_lane_share(int tile16, const float *in64, float *out64)
 {
     if (!in64 || !out64) return NNS_ERR_INVALID;

@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "nns_last_error", "nns_version", "nns_selftest_mfma",
     "nns_index_create_bf16", "nns_index_search_bf16", "nns_search_bf16_ex", "nns_search_f32_multi",
     "nns_trim", "nns_warmup", "nns_shutdown", "nns_search_bf16_multi",
-    "nns_index_near_ties", "nns_tau_consts", "nns_index_search_indices", "nns_selftest_lane_share",
+    "nns_index_near_ties", "nns_tau_consts", "nns_index_search_indices", "nns_selftest_lane_share", "nns_plan_filter",
     "nns_comm_unique_id", "nns_comm_create", "nns_comm_size", "nns_comm_allreduce_min", "nns_comm_destroy",
 )
 NNS_COMM_ID_BYTES = 128
@@ -104,6 +104,7 @@ def _load() -> ctypes.CDLL:
     lib.nns_index_near_ties.argtypes = [c_vp, c_vp, c_int, ctypes.POINTER(c_int)]
     lib.nns_tau_consts.argtypes = [c_int, ctypes.c_float, ctypes.c_float, c_int, c_vp]
     lib.nns_selftest_lane_share.argtypes = [c_int, c_vp, c_vp]
+    lib.nns_plan_filter.argtypes = [c_int, c_int, c_int, c_int, c_u, c_vp, c_int]
     lib.nns_keys_min.argtypes = [c_vp, c_vp, c_int, c_vp]
     lib.nns_keys_unpack.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
     lib.nns_fill_uniform.argtypes = [c_vp, c_sz, c_u64, c_u64, c_vp]
@@ -144,6 +145,15 @@ def selftest_mfma(a: np.ndarray, b: np.ndarray, c0: np.ndarray, bf16: bool = Fal
     _check(lib.nns_selftest_mfma(a.shape[1], int(bf16), a.ctypes.data, b.ctypes.data, c0.ctypes.data, out.ctypes.data),
            "nns_selftest_mfma")
     return out
+
+
+def plan_filter(k: int, m: int, n: int, bf16: bool = False, flags: int = 0) -> dict:
+    """nns_plan_filter: the MFMA filter's launch geometry for a shape (host only)."""
+    out = np.zeros(12, np.int32)
+    _check(lib.nns_plan_filter(k, m, n, int(bf16), flags, out.ctypes.data, 12), "nns_plan_filter")
+    names = ("kt", "bf16", "mixed", "lpq", "m_pad", "n_pad", "total_slots", "splits", "slots_per_split", "qgroups",
+             "slot_pts", "queries_per_wg")
+    return dict(zip(names, (int(v) for v in out)))
 
 
 def selftest_lane_share(values, tile16: bool) -> np.ndarray:

@@ -1,0 +1,59 @@
+"""CPU tests of the host-side planning logic behind the MFMA filter launch (nns_plan_filter, no device):
+tile depth by dimensionality and dtype, padding, and that the ref-range splits tile the ring slots exactly —
+a wrong plan here is an out-of-bounds DMA on the GPU."""
+import numpy as np
+import pytest
+
+
+def _check_plan(p, k, m, n):
+    assert p["kt"] >= k
+    assert p["m_pad"] >= m and p["m_pad"] % p["queries_per_wg"] == 0 and p["m_pad"] - m < p["queries_per_wg"]
+    assert p["qgroups"] * p["queries_per_wg"] == p["m_pad"]
+    assert p["n_pad"] >= n and p["n_pad"] % 32 == 0 and p["n_pad"] == p["total_slots"] * p["slot_pts"]
+    # splits x slots_per_split covers every slot, the last split is not empty
+    assert p["splits"] >= 1 and p["slots_per_split"] >= 1
+    assert p["splits"] * p["slots_per_split"] >= p["total_slots"] > (p["splits"] - 1) * p["slots_per_split"]
+    assert p["splits"] <= 65535
+    # candidate list memory stays bounded (512 B per lane-list)
+    assert p["splits"] * p["m_pad"] * p["lpq"] * 512 <= (2 << 30) or p["splits"] * p["qgroups"] <= 512
+
+
+def test_tile_depth_by_dimensionality(pkg):
+    want_f32 = {8: 16, 16: 16, 17: 32, 32: 32, 33: 64, 64: 64, 65: 128, 128: 128, 129: 256, 256: 256}
+    for k, kt in want_f32.items():
+        p = pkg.plan_filter(k, 1000, 50000)
+        assert (p["kt"], p["bf16"], p["mixed"]) == (kt, 0, 0), (k, p)
+    for k, kt in {257: 512, 512: 512, 513: 1024, 1024: 1024}.items():      # fp32 points beyond the fp32 tiles
+        p = pkg.plan_filter(k, 1000, 50000)
+        assert (p["kt"], p["bf16"], p["mixed"]) == (kt, 1, 1), (k, p)
+    for k, kt in {32: 128, 128: 128, 129: 256, 256: 256, 257: 512, 512: 512, 600: 1024, 1024: 1024}.items():
+        p = pkg.plan_filter(k, 1000, 50000, bf16=True)
+        assert (p["kt"], p["bf16"], p["mixed"]) == (kt, 1, 0), (k, p)
+    assert pkg.plan_filter(100, 1000, 50000, flags=pkg.NNS_FILTER_BF16)["mixed"] == 1
+    with pytest.raises(pkg.NNSError) as e:
+        pkg.plan_filter(1025, 10, 10, bf16=True)
+    assert e.value.status == 5
+
+
+def test_headline_geometries(pkg):
+    p = pkg.plan_filter(128, 65536, 1048576)                 # C3: one workgroup per CU, two ref ranges
+    assert (p["qgroups"], p["splits"], p["slot_pts"], p["queries_per_wg"], p["lpq"]) == (128, 2, 64, 512, 2)
+    p = pkg.plan_filter(256, 131072, 2097152, bf16=True)     # C5: 16x16 tiles, four lists per query
+    assert (p["qgroups"], p["splits"], p["lpq"]) == (256, 1, 4)
+    p = pkg.plan_filter(16, 1024, 1048576)                   # the reference driver's 16-D sample: 16-deep tile
+    assert (p["kt"], p["slot_pts"], p["qgroups"]) == (16, 512, 2) and p["qgroups"] * p["splits"] >= 256
+    p = pkg.plan_filter(1024, 65536, 1048576, bf16=True)     # 1024-deep: 128 queries per workgroup, blocks of two slots
+    assert (p["queries_per_wg"], p["slot_pts"]) == (128, 16) and p["slots_per_split"] % 2 == 0 and p["total_slots"] % 2 == 0
+
+
+def test_plan_invariants_random_shapes(pkg):
+    rng = np.random.default_rng(2026)
+    for _ in range(3000):
+        bf16 = bool(rng.integers(0, 2))
+        k = int(rng.integers(32 if bf16 else 8, 1025))
+        m = int(rng.choice([1, 63, 64, 65, 511, 512, 513, 4096, 65536, 200000]))
+        n = int(rng.choice([1, 31, 32, 33, 511, 513, 4097, 65536, 1000003, 8388608]))
+        p = pkg.plan_filter(k, m, n, bf16=bf16)
+        _check_plan(p, k, m, n)
+        if p["kt"] == 1024:
+            assert p["slots_per_split"] % 2 == 0 and p["total_slots"] % 2 == 0
