@@ -206,15 +206,16 @@ using OpF32K256 = OpF32T<32, 1>;
 // not hide it, measured), which cost 7-9 % of this kernel.  Two v_min per MFMA gap fit the 8
 // issue cycles a 16x16x32 leaves free, so the reduction of tile rt's finished scores is spread
 // over k-step 1 of tile 1 - rt, and the threshold test + (rare) slow path follow at k-step 2.
-template <int SPB_>
+template <int SPB_, int NW_ = NNS_F_NW_BF16, bool ASM_ = true>
 struct OpBF16T {
-    static constexpr int kSPB = SPB_;         // 16: KT = 256 (8 k-steps per 16-ref tile); 8: KT = 128 (4 k-steps)
+    static constexpr int kSPB = SPB_;         // 16: KT = 256 (8 k-steps per 16-ref tile); 8: KT = 128 (4 k-steps); 32: KT = 512
+    static constexpr bool kAsmMfma = ASM_;    // false: compiler builtins (the 512-deep form: operands beyond the 256 ArchVGPRs an asm "v" can name)
     static constexpr bool kTile16 = true;
     static constexpr bool kLag = false;       // lock-step SIMD partners (lagging them: +1..4 % time on C5)
     static constexpr bool kTauInRegs = false; // 222-234 VGPRs: the four states' constants live in LDS (read on the slow path)
     using Acc = AccSet16;
     static constexpr int kQB = 2;             // 64 queries per wave = 4 query tiles
-    static constexpr int kNW = NNS_F_NW_BF16;
+    static constexpr int kNW = NW_;
 #ifndef NNS_F_PF_BF16
 #define NNS_F_PF_BF16 2
 #endif
@@ -227,9 +228,12 @@ struct OpBF16T {
     // the epilogue's fences (mma16_fence_lo / _hi).
     __device__ static __forceinline__ void mma16(const float4 &a, const float4 &b, f32x4 &acc)
     {
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
-                     : "+v"(acc)
-                     : "v"(__builtin_bit_cast(f32x4, a)), "v"(__builtin_bit_cast(f32x4, b)));
+        if constexpr (ASM_)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                         : "+v"(acc)
+                         : "v"(__builtin_bit_cast(f32x4, a)), "v"(__builtin_bit_cast(f32x4, b)));
+        else
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
     // First MFMA of a tile: srcC = the refs' norms (three-address form).  The accumulator is an
     // in/out operand although its old value is not read: that pins every tile to ONE register
@@ -238,9 +242,12 @@ struct OpBF16T {
     // interval's last MFMAs — a read hazard (caught by tools/check_mfma_hazards.py).
     __device__ static __forceinline__ void mma16_seed(const float4 &a, const float4 &b, f32x4 &acc, const f32x4 &c)
     {
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
-                     : "+v"(acc)
-                     : "v"(__builtin_bit_cast(f32x4, a)), "v"(__builtin_bit_cast(f32x4, b)), "v"(c));
+        if constexpr (ASM_)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
+                         : "+v"(acc)
+                         : "v"(__builtin_bit_cast(f32x4, a)), "v"(__builtin_bit_cast(f32x4, b)), "v"(c));
+        else
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
     // VALU may read an accumulator 8 wait states after the MFMA that wrote it issued (what hipcc
     // inserts behind the builtin: s_nop 7).  To the compiler an asm MFMA's result is ready at
@@ -250,11 +257,17 @@ struct OpBF16T {
     // the reads are ordered behind it.
     __device__ static __forceinline__ void mma16_tail_fence(AccSet16 &c)
     {
-        asm volatile("s_nop 7" : "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13));
+        if constexpr (ASM_) asm volatile("s_nop 7" : "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13));
+        // (builtin MFMAs: hipcc's hazard recognizer places the wait states)
     }
 };
 using OpBF16 = OpBF16T<16>;       // KT = 256
 using OpBF16K128 = OpBF16T<8>;    // KT = 128: k <= 128 without padding to 256 (half the MFMAs)
+// KT = 512 in the 16x16x32 form (round 2): the resident operands of the wave's four query tiles are 256
+// registers, so four waves per workgroup (one per SIMD) = 256 queries; a 1 KiB LDS fragment still feeds FOUR
+// MFMAs (the 32x32x16 form of OpBF16K512: one — LDS-bandwidth bound at 55 % of peak).  Compiler builtins
+// instead of inline asm: an asm "v" operand must sit in the 256 architectural VGPRs.
+using OpBF16K512T = OpBF16T<32, 4, false>;
 
 
 // OpBF16T32: v_mfma_f32_32x32x16_bf16 (the first version; kept for A/B builds with
@@ -287,8 +300,10 @@ using OpBF16K512 = OpBF16T32T<32, 1>;
 using OpBF16K1024 = OpBF16T32T<64, 1, 4>;
 #if NNS_BF16_TILE16
 using OpBF16Active = OpBF16;
+using OpBF16K512Active = OpBF16K512T;
 #else
 using OpBF16Active = OpBF16T32;
+using OpBF16K512Active = OpBF16K512;
 #endif
 
 // LDS-DMA (global_load_lds_*): 64 lanes x {16, 4} bytes from per-lane global addresses to
@@ -725,7 +740,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                     // separate registers (8 v_mov at the latch, 8 more to put them back in front of the tile's
                     // seed MFMA, whose in/out constraint "reads" them): 16 of the 74 VALU instructions of an
                     // interval, in a loop where every VALU issue cycle is an MFMA issue cycle lost.
-                    asm volatile("" : "+v"(acc.template at<ot, qt>()));
+                    if constexpr (OP::kAsmMfma) asm volatile("" : "+v"(acc.template at<ot, qt>()));
                     const f32x4 o = acc.template at<ot, qt>();
                     if constexpr ((kAblate & 2) != 0) asm volatile("" ::"v"(o));
                     else tmh[qt] = fminf(fminf(fminf(o[0], o[1]), o[2]), o[3]);
@@ -1053,10 +1068,10 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
     g->bf16 = bf16 ? 1 : 0;
     g->mixed = mixed ? 1 : 0;
     g->kt = kt;
-    g->lpq = (bf16 && kt <= 256 && OpBF16Active::kTile16) ? 4 : 2;
+    g->lpq = (bf16 && kt <= 512 && OpBF16Active::kTile16) ? 4 : 2;
     // queries per workgroup
     const int qw = 32 * (bf16 ? (kt == 1024  ? OpBF16K1024::kQB * OpBF16K1024::kNW
-                              : kt == 512 ? OpBF16K512::kQB * OpBF16K512::kNW
+                              : kt == 512 ? OpBF16K512Active::kQB * OpBF16K512Active::kNW
                                           : OpBF16Active::kQB * OpBF16Active::kNW)
                               : (kt == 256 ? OpF32K256::kQB * OpF32K256::kNW : OpF32::kQB * OpF32::kNW));
     g->m_pad = divup(m, qw) * qw;
@@ -1150,7 +1165,7 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
     }
 #endif
     const int rc = g.bf16 ? (g.kt == 128    ? launch_filter_t<OpBF16K128>(g, a, st)
-                             : g.kt == 512  ? launch_filter_t<OpBF16K512>(g, a, st)
+                             : g.kt == 512  ? launch_filter_t<OpBF16K512Active>(g, a, st)
                              : g.kt == 1024 ? launch_filter_t<OpBF16K1024>(g, a, st)
                                            : launch_filter_t<OpBF16Active>(g, a, st))
                           : (g.kt == 16    ? launch_filter_t<OpF32K16>(g, a, st)

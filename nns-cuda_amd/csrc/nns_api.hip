@@ -126,7 +126,7 @@ static int prep_refs(nns_index *ix, hipStream_t st)
     const FilterGeom &g = ix->geom;
     NNS_HIP(hipMemsetAsync(ix->scal, 0, sizeof(DevScalars), st));
     if (ix->bf16) {
-        NNS_TRY(launch_prep_image_bf16((NNS_BF16_TILE16 && g.kt < 512) ? 1 : 0, g.kt, ix->k, ix->n, g.n_pad, (const uint16_t *)ix->r_dev, -2.0f, INFINITY,
+        NNS_TRY(launch_prep_image_bf16((NNS_BF16_TILE16 && g.kt <= 512) ? 1 : 0, g.kt, ix->k, ix->n, g.n_pad, (const uint16_t *)ix->r_dev, -2.0f, INFINITY,
                                        ix->rimg, ix->rnorm, &ix->scal->ymax2_bits,
                                        &ix->scal->r_maxabs_bits, st));
         return NNS_OK;
@@ -466,7 +466,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
                   "per-search scalars must be adjacent");
     NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned) + 2 * sizeof(int), st));
     if (bf16)
-        NNS_TRY(launch_prep_image_bf16((NNS_BF16_TILE16 && g.kt < 512) ? 1 : 0, g.kt, ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
+        NNS_TRY(launch_prep_image_bf16((NNS_BF16_TILE16 && g.kt <= 512) ? 1 : 0, g.kt, ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
                                        nullptr, &ix->scal->q_maxabs_bits, st));
     else
         NNS_TRY(launch_prep_image(ix->k, g.kt, m, g.m_pad, (const float *)q_dev, ix->mean, 1.0f, 0.0f,

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void image_kernel(int k, int npts, const float
 // image_bf16_kernel): the fp32 tile of image_kernel would not fit the 64 KiB of static LDS, so
 // each thread centres, squares (fp64) and rounds a 64-dim run of one point on the fly and only
 // the bf16 values are staged.  Same values as image_kernel<KT, 1> would produce.
-__global__ __launch_bounds__(256) void image_mixed512_kernel(int k, int npts, const float *__restrict__ pts,
+__global__ __launch_bounds__(256) void image_mixed512_kernel(int order, int k, int npts, const float *__restrict__ pts,
                                                              const float *__restrict__ mean, float scale,
                                                              float pad_norm, uint16_t *__restrict__ img,
                                                              float *__restrict__ norms,
@@ -329,11 +329,21 @@ __global__ __launch_bounds__(256) void image_mixed512_kernel(int k, int npts, co
             if (tid == 0) max_word(max_norm_bits, nb);
         }
     }
-    // 16-byte fragments of the 32x32x16 operand order: f = s * 64 + lane, lane = 32 h + i
+    // 16-byte fragments: f = s * 64 + lane.  order 0 (32x32x16 operands): lane = 32 h + i, dims 16 s + 8 h ..;
+    // order 1 (16x16x32 operands): fragment (KT / 32) t + ks, lane: point 16 t + (l & 15), dims 32 ks + 8 (l >> 4) ..
     uint4 *out = reinterpret_cast<uint4 *>(img + (size_t)blk * 32 * KT);
     for (int f = tid; f < (KT / 16) * 64; f += 256) {
         const int s16 = f >> 6, lane = f & 63;
-        out[f] = *reinterpret_cast<const uint4 *>(&tile[(lane & 31) * LD + 16 * s16 + 8 * (lane >> 5)]);
+        int i, d0;
+        if (order == 0) {
+            i = lane & 31;
+            d0 = 16 * s16 + 8 * (lane >> 5);
+        } else {
+            constexpr int NKS = KT / 32;
+            i = 16 * (s16 / NKS) + (lane & 15);
+            d0 = 32 * (s16 % NKS) + 8 * (lane >> 4);
+        }
+        out[f] = *reinterpret_cast<const uint4 *>(&tile[i * LD + d0]);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -436,8 +446,8 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, c
             hipLaunchKernelGGL((image_deep_kernel<1024, float>), dim3(blocks), dim3(256), 0, st, k, npts, pts, mean, scale,
                                pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
         else if (kt == 512)
-            hipLaunchKernelGGL(image_mixed512_kernel, dim3(blocks), dim3(256), 0, st, k, npts, pts, mean, scale,
-                               pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
+            hipLaunchKernelGGL(image_mixed512_kernel, dim3(blocks), dim3(256), 0, st, NNS_BF16_TILE16 ? 1 : 0, k, npts, pts, mean,
+                               scale, pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
         else if (kt == 256)
             hipLaunchKernelGGL((image_kernel<256, 1>), dim3(blocks), dim3(256), 0, st, k, npts, pts, mean, scale,
                                pad_norm, img, norms, max_norm_bits, maxabs_bits);
@@ -593,7 +603,7 @@ int launch_prep_image_bf16(int order, int kt, int k, int npts, int npts_pad, con
     if (kt == 256)
         hipLaunchKernelGGL(image_bf16_kernel<256>, dim3(npts_pad / 32), dim3(256), 0, st, order, k, npts, pts, scale,
                            pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
-    else if (kt == 512 && order == 0)
+    else if (kt == 512)   // (either operand order)
         hipLaunchKernelGGL(image_bf16_kernel<512>, dim3(npts_pad / 32), dim3(256), 0, st, order, k, npts, pts, scale,
                            pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
     else if (kt == 1024 && order == 0)
