@@ -633,14 +633,21 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             // only into a group that has one.
             const f32x16 &t = acc.template at<st>();
             const int jbase = blk_global * 32 + 4 * h;
+            // (the groups are tile_min's own triples + the sixteenth score: hipcc shares the group minima
+            //  between the two, and with any other grouping it splits the hot path's v_min3 to do so —
+            //  10 VALU instructions per retired tile instead of 8)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float gm = fminf(fminf(t[4 * g], t[4 * g + 1]), fminf(t[4 * g + 2], t[4 * g + 3]));
+            for (int g = 0; g < 5; ++g) {
+                const float gm = fminf(fminf(t[3 * g], t[3 * g + 1]), t[3 * g + 2]);
                 if (__builtin_amdgcn_ballot_w64(gm <= thr[st]) != 0ull) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) record(st_c, t[4 * g + e], jbase + e + 8 * g, roomy);   // rows (r & 3) + 8 (r >> 2)
+                    for (int e = 0; e < 3; ++e) {
+                        const int r = 3 * g + e;
+                        record(st_c, t[r], jbase + (r & 3) + 8 * (r >> 2), roomy);
+                    }
                 }
             }
+            if (__builtin_amdgcn_ballot_w64(t[15] <= thr[st]) != 0ull) record(st_c, t[15], jbase + 3 + 8 * 3, roomy);
         }
 #ifdef NNS_DIAG
         diag_cyc += __builtin_amdgcn_s_memtime() - diag_t0;
