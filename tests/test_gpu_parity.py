@@ -1183,3 +1183,55 @@ def test_bench_rccl_path_world_size_one():
     assert d["n_gpus"] == 1 and d["verified_vs_unsharded"] is True
     assert d["exchange"]["impl"].startswith("nns_comm_allreduce_min") and d["exchange"]["rccl_ranks"] == 1
     assert d["exchange"]["matches_torch_all_reduce"] is True
+
+
+def test_k1a_first_minimum_across_chunks_waves_and_splits(pkg, orc):
+    """K1a keeps (distance, chunk start) through its merges and recovers the exact index once per query: exact
+    duplicates of the winner straddling every boundary it knows — chunk (8 refs), LDS tile (1360 refs at k = 3),
+    wave round-robin, ref split — must still resolve to the LOWEST index; all-identical refs give index 0."""
+    rng = np.random.default_rng(808)
+    for k, n in ((3, 65536), (2, 40000), (16, 30000), (8, 5000)):
+        m = 700
+        q = rng.random((m, k), dtype=np.float32)
+        r = rng.random((n, k), dtype=np.float32) + np.float32(2.0)      # far from the queries
+        hot = rng.random((1, k), dtype=np.float32)
+        # the same nearest point at positions on both sides of every kind of boundary
+        for pos in (7, 8, 1359, 1360, 4095, 4096, 4097, n // 2 - 1, n // 2, n - 1):
+            r[pos] = hot
+        q[:350] = hot + rng.normal(0, 1e-3, (350, k)).astype(np.float32)
+        want_idx, want_dist = orc.v0_search(q, r, threads=8)
+        assert (want_idx[:350] == 7).all()
+        for shards in (1, 3):
+            idx, dist = pkg.search(q, r, return_distances=True, shards=shards, path="exact")
+            assert np.array_equal(idx, want_idx), (k, n, shards)
+            assert np.array_equal(_bits(dist), _bits(want_dist))
+        r2 = r.copy()
+        r2[7] = r2[9]                                                  # now the first copy sits at index 8
+        assert (pkg.search(q[:350], r2, path="exact") == 8).all()
+    same = np.tile(rng.random((1, 3), dtype=np.float32), (100000, 1))
+    assert (pkg.search(rng.random((300, 3), dtype=np.float32), same) == 0).all()
+
+
+def test_deep_tile_specials_and_whole_call_bf16_pipeline(pkg, orc):
+    """The 1024-deep tile with NaN / INF refs and magnitudes that void the error bound (exact kernels must take
+    over), and a bf16 whole call large enough for the pipelined upload."""
+    rng = np.random.default_rng(909)
+    m, n, k = 130, 4000, 700
+    q = rng.random((m, k), dtype=np.float32)
+    r = rng.random((n, k), dtype=np.float32)
+    r[17, 600] = np.nan
+    r[3000, 5] = np.inf
+    q[4, 650] = np.nan
+    with np.errstate(all="ignore"):
+        _check(pkg, orc, q, r, paths=("auto",), shards=(1, 2))
+        _check_bf16(pkg, orc, q, r, paths=("auto", "mfma"), shards=(1, 2))
+        big = (rng.random((m, k), dtype=np.float32) * np.float32(3e18), rng.random((n, k), dtype=np.float32) * np.float32(3e18))
+        _check(pkg, orc, big[0], big[1], paths=("auto",), shards=(1,))
+    m, n, k = 8192, 262144, 256                                       # 128 MiB of bf16 refs: pipelined
+    q = orc.round_bf16(orc.rng_uniform(m * k, 92, 0).reshape(m, k))
+    r = orc.round_bf16(orc.rng_uniform(n * k, 92, m * k).reshape(n, k))
+    r[n - 3] = r[5]
+    q[0] = r[5]
+    want_idx, want_dist = orc.v0_search(q, r, threads=16)
+    idx, dist = pkg.search_bf16(pkg.to_bf16_bits(q), pkg.to_bf16_bits(r), return_distances=True)
+    assert np.array_equal(idx, want_idx) and np.array_equal(_bits(dist), _bits(want_dist))
