@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -681,7 +682,6 @@ struct Stager {
     hipEvent_t done[NB] = {};
     bool used[NB] = {};
     hipStream_t copy = nullptr;
-    int next = 0;
     int threads = 4;
     int device = 0;
     bool ok = false;
@@ -694,7 +694,7 @@ struct Stager {
                 return NNS_ERR_NOMEM;
         if (hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) return NNS_ERR_HIP;
         const unsigned hw = std::thread::hardware_concurrency();
-        threads = hw >= 8 ? 4 : (hw >= 4 ? 2 : 1);
+        threads = hw >= 8 ? NB : (hw >= 4 ? 2 : 1);   // staging workers (<= NB: one pinned buffer each)
         ok = true;
         return NNS_OK;
     }
@@ -709,35 +709,34 @@ struct Stager {
             if (pinned[b]) (void)hipHostFree(pinned[b]);
         }
     }
-    // host -> device, asynchronous on the copy stream (returns once the last piece is STAGED, not landed)
+    // host -> device, asynchronous on the copy stream (returns once the last piece is STAGED and its copy
+    // ISSUED, not landed).  Pieces of BUF bytes go round-robin to up to NB staging workers, each with its own
+    // pinned buffer: memcpy into it (once the buffer's previous copy has drained), issue the async copy, record
+    // the buffer's event.  The order in which the pieces' copies reach the stream does not matter: the caller
+    // records its "landed" event behind all of them.
     int upload(void *dst, const void *src, size_t bytes)
     {
-        for (size_t off = 0; off < bytes; off += BUF) {
-            const size_t piece = bytes - off < BUF ? bytes - off : BUF;
-            const int b = next;
-            next = (next + 1) % NB;
-            if (used[b] && hipEventSynchronize(done[b]) != hipSuccess) return NNS_ERR_HIP;   // the buffer's last copy has drained
-            const char *sp = (const char *)src + off;
-            char *dp = (char *)pinned[b];
-            const int nt = piece >= ((size_t)4 << 20) ? threads : 1;
-            if (nt > 1) {
-                std::vector<std::thread> th;
-                const size_t per = (piece / nt + 4095) & ~(size_t)4095;
-                for (int t = 1; t < nt; ++t) {
-                    const size_t a = (size_t)t * per, e = a + per < piece ? a + per : piece;
-                    if (a < e) th.emplace_back([=] { memcpy(dp + a, sp + a, e - a); });
-                }
-                memcpy(dp, sp, per < piece ? per : piece);
-                for (auto &t : th) t.join();
-            } else {
-                memcpy(dp, sp, piece);
+        const size_t npieces = (bytes + BUF - 1) / BUF;
+        const int nt = (int)(npieces < (size_t)threads ? npieces : (size_t)threads);
+        std::atomic<int> failed{0};
+        auto work = [&](int t) {
+            (void)hipSetDevice(device);
+            for (size_t p = (size_t)t; p < npieces && !failed.load(std::memory_order_relaxed); p += (size_t)nt) {
+                const size_t off = p * BUF, piece = bytes - off < BUF ? bytes - off : BUF;
+                const int b = t;                     // worker t owns buffer t
+                if (used[b] && hipEventSynchronize(done[b]) != hipSuccess) failed = 1;
+                memcpy(pinned[b], (const char *)src + off, piece);
+                if (hipMemcpyAsync((char *)dst + off, pinned[b], piece, hipMemcpyHostToDevice, copy) != hipSuccess ||
+                    hipEventRecord(done[b], copy) != hipSuccess)
+                    failed = 1;
+                used[b] = true;
             }
-            if (hipMemcpyAsync((char *)dst + off, pinned[b], piece, hipMemcpyHostToDevice, copy) != hipSuccess ||
-                hipEventRecord(done[b], copy) != hipSuccess)
-                return NNS_ERR_HIP;
-            used[b] = true;
-        }
-        return NNS_OK;
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &t : th) t.join();
+        return failed.load() ? NNS_ERR_HIP : NNS_OK;
     }
 };
 
