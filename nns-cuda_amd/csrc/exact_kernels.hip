@@ -343,9 +343,13 @@ static K1aPlan k1a_plan(int m, int n)
     while (nw > 1 && (int64_t)nw * 4 * CH > n) nw >>= 1;
     if (nw < 1) nw = 1;
     p.nw = nw;
-    // ref splits: the rest of the way to the target, >= 64 refs per wave
+    // ref splits: the rest of the way to the target, >= 16 refs per wave (small problems are launch-bound: a
+    // finer cut spreads 1024 x 4096 x 3 over 128 workgroups instead of 32: 12 -> 8 us; 512 x 8192 x 16: 46 -> 26)
     int splits = divup(NNS_K1A_WAVES, p.qtiles * nw);
-    const int max_splits = divup(n, 64 * nw);
+#ifndef NNS_K1A_MIN_REFS_PER_WAVE
+#define NNS_K1A_MIN_REFS_PER_WAVE 16
+#endif
+    const int max_splits = divup(n, (NNS_K1A_MIN_REFS_PER_WAVE) * nw);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
