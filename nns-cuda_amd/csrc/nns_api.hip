@@ -1014,11 +1014,14 @@ int nns_search_bf16_ex(int k, int m, int n, const uint16_t *s_points, const uint
 int nns_warmup(int device)
 {
     NNS_TRY(ensure_device_ok(device));
-    // (k, m, n, bf16): K1a, K1b, the fp32 tile depths 16 / 32 / 64 / 128 / 256, the bf16-operand tiles for fp32
-    // points (512 / 1024), the bf16 tiles 128 / 256 / 512 / 1024
-    static const int shapes[][4] = {{3, 64, 512, 0},   {16, 1, 512, 0},   {16, 64, 512, 0},  {24, 64, 512, 0}, {40, 64, 512, 0},
-                                    {100, 64, 512, 0}, {200, 64, 512, 0}, {300, 64, 512, 0}, {600, 64, 512, 0}, {64, 64, 512, 1},
-                                    {200, 64, 512, 1}, {300, 64, 512, 1}, {600, 64, 512, 1}};
+    // (k, m, n, bf16, path): K1a (3-D and 16-D), K1b, the fp32 tile depths 16 / 32 / 64 / 128 / 256 (forced onto the
+    // filter: AUTO keeps a 64 x 512 x 16 problem on the exact kernel), the bf16-operand tiles for fp32 points (512 /
+    // 1024: AUTO), the bf16 tiles 128 / 256 / 512 / 1024
+    static const int shapes[][5] = {{3, 64, 512, 0, NNS_PATH_AUTO},    {16, 64, 512, 0, NNS_PATH_AUTO},  {16, 1, 512, 0, NNS_PATH_AUTO},
+                                    {16, 64, 512, 0, NNS_PATH_MFMA},   {24, 64, 512, 0, NNS_PATH_MFMA},  {40, 64, 512, 0, NNS_PATH_MFMA},
+                                    {100, 64, 512, 0, NNS_PATH_MFMA},  {200, 64, 512, 0, NNS_PATH_MFMA}, {300, 64, 512, 0, NNS_PATH_AUTO},
+                                    {600, 64, 512, 0, NNS_PATH_AUTO},  {64, 64, 512, 1, NNS_PATH_MFMA},  {200, 64, 512, 1, NNS_PATH_MFMA},
+                                    {300, 64, 512, 1, NNS_PATH_MFMA},  {600, 64, 512, 1, NNS_PATH_MFMA}};
     const int kmax = 600, mmax = 64, nmax = 512;
     float *q = (float *)malloc(sizeof(float) * kmax * mmax), *r = (float *)malloc(sizeof(float) * kmax * nmax);
     int *idx = (int *)malloc(sizeof(int) * mmax);
@@ -1048,14 +1051,14 @@ int nns_warmup(int device)
                     memcpy(&u, &r[i], 4);
                     rb[i] = (uint16_t)(u >> 16);
                 }
-                rc = search_host_impl(sh[0], sh[1], sh[2], qb, rb, 1, idx, nullptr, 1, NNS_PATH_AUTO, device);
+                rc = search_host_impl(sh[0], sh[1], sh[2], qb, rb, 1, idx, nullptr, 1, (unsigned)sh[4], device);
             } else {
                 rc = NNS_ERR_NOMEM;
             }
             free(qb);
             free(rb);
         } else {
-            rc = search_host_impl(sh[0], sh[1], sh[2], q, r, 0, idx, nullptr, 1, NNS_PATH_AUTO, device);
+            rc = search_host_impl(sh[0], sh[1], sh[2], q, r, 0, idx, nullptr, 1, (unsigned)sh[4], device);
         }
         if (rc != NNS_OK) break;
     }
