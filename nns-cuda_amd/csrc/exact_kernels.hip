@@ -121,10 +121,10 @@ __device__ __forceinline__ nns_key wave_min_key(nns_key v)
 // K1a: lane = query, wave-uniform refs
 // ---------------------------------------------------------------------------
 // K1a geometry: a lane holds QPL queries in registers; a workgroup of NW waves (all NW waves hold the SAME
-// 64 x QPL queries) stages a tile of its ref range in LDS (coalesced) and its waves walk the tile's chunks
-// of CH refs round-robin, each chunk read by BROADCAST ds_read_b128 (all lanes, same address: one LDS
-// access, no bank conflict).  (Reading the wave-uniform refs through the scalar cache instead thrashes
-// it: the co-resident workgroups stream different ref ranges through 16 KiB.)
+// 64 x QPL queries) walks its ref range in chunks of CH refs, the waves round-robin.  K <= 4: the workgroup
+// stages a tile of the range in LDS (coalesced) and a chunk is read by BROADCAST ds_read_b128 (all lanes, same
+// address: one LDS access, no bank conflict).  K >= 8: a chunk is 32 floats — the wave fetches it itself with
+// scalar loads (wave-uniform address) and the refs feed the VALU as SGPR operands.
 //
 // The inner loop is branch-free: per pair the 3K - 1 V0 operations (the first add of the chain is
 // 0 + x = x, exact), per chunk a min tree and TWO conditional moves — the lane's best distance and the
@@ -146,6 +146,9 @@ __device__ __forceinline__ nns_key wave_min_key(nns_key v)
 #ifndef NNS_K1A_QPL
 #define NNS_K1A_QPL 2
 #endif
+// refs through the scalar cache (K >= 8) or through an LDS tile (K <= 4): see the kernel
+template <int K>
+constexpr bool kK1aScalarRefs = K >= 8;
 constexpr int K1A_QPL = NNS_K1A_QPL;   // queries per lane
 #ifndef NNS_K1A_LDS_FLOATS
 #define NNS_K1A_LDS_FLOATS 4096
@@ -239,25 +242,13 @@ __global__ __launch_bounds__(64 * K1A_MAXNW) void exact_lane_query_kernel(
         bchunk[u] = j0;
     }
 
-    for (int t0 = j0; t0 < j1; t0 += TILE) {
-        const int cnt = (j1 - t0) < TILE ? (j1 - t0) : TILE;
-        __syncthreads();
-        for (int e = threadIdx.x; e < cnt * K; e += nthreads) sref[e] = r[(size_t)t0 * K + e];   // coalesced
-        // a ragged last chunk is padded with NaN coordinates: its distances are NaN, never selected
-        const int padded = (cnt + CH - 1) / CH * CH;   // <= TILE (a multiple of CH)
-        for (int e = cnt * K + threadIdx.x; e < padded * K; e += nthreads) sref[e] = __builtin_nanf("");
-        __syncthreads();
-        for (int c = wave * CH; c < cnt; c += nw * CH) {
-            float cf[NF];
-            const float4 *src = reinterpret_cast<const float4 *>(sref + c * K);   // uniform address
-#pragma unroll
-            for (int e = 0; e < NF / 4; ++e) {
-                const float4 v = src[e];
-                cf[4 * e + 0] = v.x;
-                cf[4 * e + 1] = v.y;
-                cf[4 * e + 2] = v.z;
-                cf[4 * e + 3] = v.w;
-            }
+    // K >= 8: refs straight from global memory through the scalar cache: the wave's chunks are wave-uniform
+    // addresses -> s_load_dwordx8/x16, the refs arrive in SGPRs and feed the VALU as scalar operands; no LDS tile,
+    // no barriers.  Two chunk buffers ping-pong so that the next chunk's loads are in flight while the current one
+    // is walked.  (Measured: 4096 x 4096 x 16 49.9 -> 41.5 us, 1024 x 4096 x 8 15.8 -> 13.6 us; at K = 3 the LDS tile
+    // below is 5 % faster: 52.1 vs 54.6 us at C2 — so the choice is by K.)
+    if constexpr (kK1aScalarRefs<K>) {
+        auto walk = [&](const float (&cf)[NF], int cbase) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < K1A_QPL; ++u) {
                 float d[CH];
@@ -270,10 +261,80 @@ __global__ __launch_bounds__(64 * K1A_MAXNW) void exact_lane_query_kernel(
                 }
                 float cmin = d[0];
 #pragma unroll
-                for (int cc = 1; cc < CH; ++cc) cmin = fminf(cmin, d[cc]);   // NaN-ignoring min
-                const bool imp = cmin < best[u];                             // false for NaN / INF; strict: first chunk wins
+                for (int cc = 1; cc < CH; ++cc) cmin = fminf(cmin, d[cc]);
+                const bool imp = cmin < best[u];
                 best[u] = imp ? cmin : best[u];
-                bchunk[u] = imp ? t0 + c : bchunk[u];
+                bchunk[u] = imp ? cbase : bchunk[u];
+            }
+        };
+        auto fetch = [&](float (&cf)[NF], int c) __attribute__((always_inline)) {
+            const float *p = r + (size_t)__builtin_amdgcn_readfirstlane(c) * K;   // wave-uniform
+#pragma unroll
+            for (int e = 0; e < NF; ++e) cf[e] = p[e];
+        };
+        {
+            const int stride = nw * CH;
+            const int full_end = j0 + (j1 - j0) / CH * CH;     // chunks [c, c + CH) with c + CH <= full_end are whole
+            int c = j0 + wave * CH;
+            float ca[NF], cb[NF];
+            if (c + CH <= full_end) fetch(ca, c);
+            while (c + CH <= full_end) {
+                const int c1 = c + stride;
+                if (c1 + CH <= full_end) fetch(cb, c1);
+                walk(ca, c);
+                if (c1 + CH > full_end) { c = c1; break; }
+                const int c2 = c1 + stride;
+                if (c2 + CH <= full_end) fetch(ca, c2);
+                walk(cb, c1);
+                c = c2;
+            }
+            // the ragged last chunk of the range (n not a multiple of CH): one wave, refs one by one
+            if (full_end < j1 && wave == ((full_end - j0) / CH) % nw) {
+                float ct[NF];
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc)
+#pragma unroll
+                    for (int t = 0; t < K; ++t) ct[cc * K + t] = full_end + cc < j1 ? r[(size_t)(full_end + cc) * K + t] : __builtin_nanf("");
+                walk(ct, full_end);
+            }
+        }
+    } else {
+        for (int t0 = j0; t0 < j1; t0 += TILE) {
+            const int cnt = (j1 - t0) < TILE ? (j1 - t0) : TILE;
+            __syncthreads();
+            for (int e = threadIdx.x; e < cnt * K; e += nthreads) sref[e] = r[(size_t)t0 * K + e];   // coalesced
+            // a ragged last chunk is padded with NaN coordinates: its distances are NaN, never selected
+            const int padded = (cnt + CH - 1) / CH * CH;   // <= TILE (a multiple of CH)
+            for (int e = cnt * K + threadIdx.x; e < padded * K; e += nthreads) sref[e] = __builtin_nanf("");
+            __syncthreads();
+            for (int c = wave * CH; c < cnt; c += nw * CH) {
+                float cf[NF];
+                const float4 *src = reinterpret_cast<const float4 *>(sref + c * K);   // uniform address
+#pragma unroll
+                for (int e = 0; e < NF / 4; ++e) {
+                    const float4 v = src[e];
+                    cf[4 * e + 0] = v.x;
+                    cf[4 * e + 1] = v.y;
+                    cf[4 * e + 2] = v.z;
+                    cf[4 * e + 3] = v.w;
+                }
+#pragma unroll
+                for (int u = 0; u < K1A_QPL; ++u) {
+                    float d[CH];
+#pragma unroll
+                    for (int cc = 0; cc < CH; ++cc) {
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int t = 0; t < K; ++t) sum = v0_step(sum, qv[u][t], cf[cc * K + t]);
+                        d[cc] = sum;
+                    }
+                    float cmin = d[0];
+#pragma unroll
+                    for (int cc = 1; cc < CH; ++cc) cmin = fminf(cmin, d[cc]);   // NaN-ignoring min
+                    const bool imp = cmin < best[u];                             // false for NaN / INF; strict: first chunk wins
+                    best[u] = imp ? cmin : best[u];
+                    bchunk[u] = imp ? t0 + c : bchunk[u];
+                }
             }
         }
     }
