@@ -48,7 +48,7 @@ static const unsigned kCreateNoSync = 1u << 30;
 // ... and a small problem in a dimensionality the lane-per-query exact kernel is instantiated for (8, 16)
 // is faster there than through the filter's fixed costs (K2 on both clouds, filter ramp, K5: ~55 us):
 // the reference driver's 16-D 1024 x 1024 sample (main.cu:44) takes 9 us instead of 57
-static const int64_t kSmallPairs = (int64_t)1 << 24;
+static const int64_t kSmallPairs = (int64_t)1 << 25;
 static bool small_exact(int k, int64_t m, int64_t n) { return (k == 8 || k == 16) && m >= kTinyM && m * n <= kSmallPairs; }
 // deepest dimensionality the MFMA filter tiles (bf16 operands; fp32 operands: 256)
 static const int kMaxFilterK = 1024;
