@@ -92,8 +92,8 @@ def self_launch(n):
 
 
 def cpu_baseline(orc, q_h, r_h, idx_gpu, target_s=12.0, full=False):
-    """V0 on the host, single thread, on a bounded sample: the first `s` queries of the
-    workload against ALL of this GPU's refs (`full`: every query).  Uses the reference's own V0
+    """V0 on the host, single thread, on a bounded sample: `s` of the randomly chosen queries handed in
+    (baseline_sample) against ALL of this GPU's refs (`full`: every one of them).  Uses the reference's own V0
     binary when it was built (oracle/_ref), else our restatement.  Also cross-checks the GPU indices."""
     n = r_h.shape[0]
     use_ref = orc.have_reference()
@@ -115,7 +115,7 @@ def cpu_baseline(orc, q_h, r_h, idx_gpu, target_s=12.0, full=False):
     ok = bool(np.array_equal(idx, idx_gpu[:s]))
     out = {"value": s * n / t, "unit": "pairs/s", "cores": 1,
            "kind": "reference" if use_ref else "port",
-           "sample": f"{'all' if full else 'first'} {s} queries x all {n} refs of the workload, {t:.1f} s, V0 single thread"
+           "sample": f"{'all' if full and s == q_h.shape[0] else 'random'} {s} queries x all {n} refs of the workload, {t:.1f} s, V0 single thread"
                      f"{' (reference core.cu:11-54 built -O2 -ffp-contract=off)' if use_ref else ''}",
            "matches_gpu_indices": ok}
     # all host cores (OpenMP over queries, our restatement) for scale
@@ -147,6 +147,17 @@ def cpu_baseline(orc, q_h, r_h, idx_gpu, target_s=12.0, full=False):
                          "cores": cores, "kind": "port", "queries": int(q_h.shape[0]), "seconds": t3,
                          "matches_gpu_indices": bool(np.array_equal(idx3, idx_gpu[:q_h.shape[0]]))}
     return out
+
+
+def baseline_sample(q, idx, cap=4096, seed=1000):
+    """Up to `cap` RANDOMLY chosen queries of the workload (fixed seed; all of them when m <= cap) and the GPU's
+    indices for them: what the CPU baseline times and cross-checks."""
+    m = q.shape[0]
+    if m <= cap:
+        return q.float().cpu().numpy(), idx.cpu().numpy()
+    sel = np.random.default_rng(seed).choice(m, cap, replace=False)      # (unsorted: any prefix of it is random too)
+    sel_t = torch.from_numpy(sel).to(q.device)
+    return q[sel_t].float().cpu().numpy(), idx[sel_t].cpu().numpy()
 
 
 def load_traffic(kernel_key):
@@ -432,8 +443,8 @@ def main():
         orc = None
         if world == 1 and not args.no_cpu_baseline:
             orc = graft.load_oracle()          # cpu_baseline leg only
-            out["cpu_baseline"] = cpu_baseline(orc, q[:4096].float().cpu().numpy(), r.float().cpu().numpy(),
-                                               idx.cpu().numpy())
+            qs, is_ = baseline_sample(q, idx)
+            out["cpu_baseline"] = cpu_baseline(orc, qs, r.float().cpu().numpy(), is_)
     ix.close()
     del q, r, keys, ix
     torch.cuda.empty_cache()
@@ -447,8 +458,8 @@ def main():
                    "dtype": o["dtype"], "config": o["config"], "roofline": o["roofline"]}
             if orc is not None:
                 full = name == "c1"            # C1 is the reference's CPU-runnable case: V0 over the whole problem
-                ent["cpu_baseline"] = cpu_baseline(orc, q2[:4096].float().cpu().numpy(), r2.float().cpu().numpy(),
-                                                   idx2.cpu().numpy(), target_s=4.0, full=full)
+                qs, is_ = baseline_sample(q2, idx2)
+                ent["cpu_baseline"] = cpu_baseline(orc, qs, r2.float().cpu().numpy(), is_, target_s=4.0, full=full)
             also[name] = ent
             ix2.close()
             del q2, r2, keys2, ix2
