@@ -87,8 +87,20 @@ def self_launch(n):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "1")        # what torchrun would set, without its warning
-    proc = subprocess.run(cmd, env=env)           # stdout / stderr inherited: rank 0's JSON line is ours
-    raise SystemExit(proc.returncode)
+    # stdout / stderr inherited: rank 0's JSON line is ours.  The launcher and its ranks get their own process
+    # group, so that a SIGTERM / SIGINT to this process (a driver's timeout) takes exactly them down with it
+    import signal
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def _forward(signum, _frame):
+        try:
+            os.killpg(proc.pid, signum)
+        except ProcessLookupError:
+            pass
+
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, _forward)
+    raise SystemExit(proc.wait())
 
 
 def cpu_baseline(orc, q_h, r_h, idx_gpu, target_s=12.0, full=False):
@@ -317,6 +329,8 @@ def selftest_launch(args):
         want = kk if want is None else torch.minimum(want, kk)
     ok = torch.tensor([1 if torch.equal(keys, want) else 0])
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if args.selftest_sleep > 0:
+        time.sleep(args.selftest_sleep)       # (tests/test_bench_launch.py: signal forwarding)
     if rank == 0:
         print(json.dumps({"selftest": "launch", "n_gpus": world, "ok": bool(ok.item()),
                           "note": "gloo rendezvous + key exchange only: not a measurement"}), flush=True)
@@ -338,6 +352,7 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=("auto", "library", "torch"),
                     help="N > 1: who issues the RCCL min all-reduce (auto: the library, torch.distributed if that fails)")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--selftest-sleep", type=float, default=0.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ

@@ -43,3 +43,21 @@ def test_bench_propagates_a_failing_rank(built):
     assert out.returncode != 0
     assert "needs a HIP device" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_self_launched_ranks_die_with_the_parent(built):
+    """A driver that times out sends SIGTERM to `python bench.py --gpus N`: the launcher and its ranks (their own
+    process group) must go down with it, not linger holding GPUs."""
+    import signal
+    import time
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                             "--selftest-launch", "--selftest-sleep", "60"],
+                            cwd=ROOT, env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(8)                                     # ranks are up and sleeping
+    import psutil
+    kids = psutil.Process(proc.pid).children(recursive=True)
+    assert len(kids) >= 3                             # the launcher + 2 ranks
+    proc.send_signal(signal.SIGTERM)
+    proc.wait(timeout=60)
+    gone, alive = psutil.wait_procs(kids, timeout=30)
+    assert not alive, [p.cmdline()[:4] for p in alive]
