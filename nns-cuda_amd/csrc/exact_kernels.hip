@@ -18,6 +18,12 @@
 //   K1b  lane = ref     (few queries or large k): a tile of queries in LDS read
 //        by broadcast, each lane walks its own ref row; used for the exact
 //        re-rank of ambiguous queries behind the MFMA filter and for m ~ 1.
+#ifdef NNS_K1A_STAMPS
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+#endif
 #include "nns_internal.h"
 
 namespace nns {
@@ -160,6 +166,12 @@ constexpr int K1A_LDS_FLOATS = NNS_K1A_LDS_FLOATS;   // 16 KiB ref tile
 #ifndef NNS_K1A_MAXNW
 #define NNS_K1A_MAXNW 16     // waves per workgroup, at most
 #endif
+#ifndef NNS_K1A_NW
+#define NNS_K1A_NW 8         // waves per workgroup, normally (k1a_plan)
+#endif
+#ifndef NNS_K1A_MIN_REFS_PER_WAVE
+#define NNS_K1A_MIN_REFS_PER_WAVE 16
+#endif
 constexpr int K1A_MAXNW = NNS_K1A_MAXNW;
 
 template <int K>
@@ -174,7 +186,19 @@ struct K1aMerge {
     int splits;
     int *idx_out;       // optional fused unpack of the final keys
     float *dist_out;
+#ifdef NNS_K1A_STAMPS
+    unsigned long long *stamps;   // diagnostic builds only: [workgroup][16] s_memrealtime stamps (100 MHz)
+#endif
 };
+#ifdef NNS_K1A_STAMPS
+#define K1A_STAMP(i)                                                                                         \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && mg.stamps)                                                                   \
+            mg.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define K1A_STAMP(i)
+#endif
 
 template <int K>
 __device__ __forceinline__ void write_final(const K1aMerge &mg, nns_key *keys, int qi, nns_key key,
@@ -211,17 +235,26 @@ __device__ __forceinline__ void write_final(const K1aMerge &mg, nns_key *keys, i
     }
 }
 
-template <int K>
-__global__ __launch_bounds__(64 * K1A_MAXNW) void exact_lane_query_kernel(
+// MAXNW = 8 / 16: the same code under two launch bounds — with the grid, block size and ISA unchanged, the C2
+// launch of 8-wave workgroups runs 2.5 us (5 %) faster when the kernel is DECLARED for at most 512 threads than
+// for 1024 (measured A/B on one device; the only difference in the code object is max_flat_workgroup_size)
+template <int K, int MAXNW>
+__global__ __launch_bounds__(64 * MAXNW) void exact_lane_query_kernel(
     int m, int n, int refs_per_split, const float *__restrict__ q,
     const float *__restrict__ r, int64_t index_base, nns_key *__restrict__ keys, const K1aMerge mg)
 {
     constexpr int CH = K1aChunk<K>::value;
     constexpr int NF = CH * K;                       // floats per chunk (multiple of 8)
-    constexpr int TILE = K1A_LDS_FLOATS / K / CH * CH;   // refs per LDS tile (multiple of CH)
+    // refs per LDS tile: a multiple of 16 chunks, so that up to 16 waves get the same number of chunks of a full tile
+    constexpr int TILE = K1A_LDS_FLOATS / K / (16 * CH) * (16 * CH);
     constexpr int QW = 64 * K1A_QPL;                 // queries per workgroup
-    __shared__ __attribute__((aligned(16))) float sref[TILE * K];
-    __shared__ nns_key wkeys[K1A_MAXNW][QW];
+    __shared__ __attribute__((aligned(16))) float sref[(kK1aScalarRefs<K> ? 1 : 2) * TILE * K];   // two tile buffers
+    // the waves' packed keys for the merge at the end: K <= 4 re-uses the tile buffers (>= 16 KiB, idle by then)
+    constexpr bool kOwnKeys = kK1aScalarRefs<K>;
+    __shared__ nns_key wkeys_own[kOwnKeys ? MAXNW : 1][QW];
+    nns_key(*const wkeys)[QW] = kOwnKeys ? wkeys_own : reinterpret_cast<nns_key(*)[QW]>(sref);
+    static_assert(kK1aScalarRefs<K> || sizeof(sref) >= sizeof(nns_key) * MAXNW * QW, "merge keys fit the tile buffers");
+    __shared__ __attribute__((aligned(16))) float sq[kK1aScalarRefs<K> ? 4 : QW * K];   // the workgroup's queries (K <= 4)
     __shared__ int s_last;
     const int nthreads = blockDim.x, nw = nthreads >> 6;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -229,6 +262,11 @@ __global__ __launch_bounds__(64 * K1A_MAXNW) void exact_lane_query_kernel(
     int j1 = j0 + refs_per_split;
     if (j1 > n) j1 = n;
 
+    K1A_STAMP(0);
+#ifdef NNS_K1A_STAMPS
+    if ((threadIdx.x & 63) == 0 && mg.stamps)
+        mg.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + 16 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();
+#endif
     int qi[K1A_QPL];
     float qv[K1A_QPL][K];
     float best[K1A_QPL];
@@ -236,8 +274,11 @@ __global__ __launch_bounds__(64 * K1A_MAXNW) void exact_lane_query_kernel(
 #pragma unroll
     for (int u = 0; u < K1A_QPL; ++u) {
         qi[u] = blockIdx.x * QW + u * 64 + lane;
+        // (K <= 4: the workgroup's queries come through LDS, below)
+        if constexpr (kK1aScalarRefs<K>) {
 #pragma unroll
-        for (int t = 0; t < K; ++t) qv[u][t] = (qi[u] < m) ? q[(size_t)qi[u] * K + t] : 0.0f;
+            for (int t = 0; t < K; ++t) qv[u][t] = (qi[u] < m) ? q[(size_t)qi[u] * K + t] : 0.0f;
+        }
         best[u] = __builtin_inff();
         bchunk[u] = j0;
     }
@@ -299,17 +340,58 @@ __global__ __launch_bounds__(64 * K1A_MAXNW) void exact_lane_query_kernel(
             }
         }
     } else {
-        for (int t0 = j0; t0 < j1; t0 += TILE) {
+        // Tiles of the ref range through a DOUBLE-BUFFERED LDS image filled by LDS-DMA (global_load_lds_dword:
+        // no registers, no wait at the issue): tile i + 1 is in flight while tile i is walked, ONE barrier per
+        // tile.
+        // copy `nvalid` floats src -> dst (LDS), then pad up to `npad` with `pad`: 16-byte DMA pieces where source
+        // and count allow (1 KiB per wave-instruction; the DMA path takes ~100 cycles per INSTRUCTION whatever
+        // its width, and a C2 launch starts with 150 of them per CU), dword pieces for an unaligned source and
+        // for the last, partial piece (never a byte beyond src + nvalid is read)
+        auto lds_fill = [&](const float *src, float *dst, int nvalid, int npad, float pad) __attribute__((always_inline)) {
+            const unsigned dst_lds = (unsigned)(uintptr_t)dst;
+            const int n4 = (((uintptr_t)src & 15) == 0) ? (nvalid & ~3) : 0;   // (wave-uniform)
+            for (int e0 = wave * 256; e0 < n4; e0 += nthreads * 4) {
+                const int e = e0 + lane * 4;
+                if (e < n4) dma16(src + e, dst_lds + (unsigned)e0 * 4u);
+            }
+            for (int e0 = n4 + wave * 64; e0 < npad; e0 += nthreads) {
+                const int e = e0 + lane;
+                if (e < nvalid) dma4(src + e, dst_lds + (unsigned)e0 * 4u);
+                else if (e < npad) dst[e] = pad;
+            }
+        };
+        auto stage = [&](int t0, int buf) __attribute__((always_inline)) {
             const int cnt = (j1 - t0) < TILE ? (j1 - t0) : TILE;
-            __syncthreads();
-            for (int e = threadIdx.x; e < cnt * K; e += nthreads) sref[e] = r[(size_t)t0 * K + e];   // coalesced
             // a ragged last chunk is padded with NaN coordinates: its distances are NaN, never selected
-            const int padded = (cnt + CH - 1) / CH * CH;   // <= TILE (a multiple of CH)
-            for (int e = cnt * K + threadIdx.x; e < padded * K; e += nthreads) sref[e] = __builtin_nanf("");
-            __syncthreads();
+            lds_fill(r + (size_t)t0 * K, sref + buf * (TILE * K), cnt * K, (cnt + CH - 1) / CH * CH * K, __builtin_nanf(""));
+        };
+        // The workgroup's 64 x QPL queries, ONCE, through LDS as well (all its waves hold the same queries: read
+        // per wave from global memory they were 16 x (waves) x splits redundant, 12-byte-strided requests)
+        {
+            const int64_t qbase = (int64_t)blockIdx.x * QW * K, qleft = (int64_t)m * K - qbase;
+            lds_fill(q + qbase, sq, qleft < QW * K ? (int)qleft : QW * K, QW * K, 0.0f);
+        }
+        stage(j0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of the queries and of tile 0 have landed
+#ifdef NNS_K1A_STAMPS
+        if (lane == 0 && mg.stamps)
+            mg.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + 32 + wave] = __builtin_amdgcn_s_memrealtime();
+#endif
+        __syncthreads();                                   // everyone's have
+        K1A_STAMP(1);
+#pragma unroll
+        for (int u = 0; u < K1A_QPL; ++u)
+#pragma unroll
+            for (int t = 0; t < K; ++t) qv[u][t] = sq[(u * 64 + lane) * K + t];
+        int buf = 0;
+        for (int t0 = j0; t0 < j1; t0 += TILE, buf ^= 1) {
+            const int cnt = (j1 - t0) < TILE ? (j1 - t0) : TILE;
+            const bool more = t0 + TILE < j1;
+            if (more) stage(t0 + TILE, buf ^ 1);   // (that buffer's tile was finished before the last barrier)
+            const float *tile = sref + buf * (TILE * K);
             for (int c = wave * CH; c < cnt; c += nw * CH) {
                 float cf[NF];
-                const float4 *src = reinterpret_cast<const float4 *>(sref + c * K);   // uniform address
+                const float4 *src = reinterpret_cast<const float4 *>(tile + c * K);   // uniform address
 #pragma unroll
                 for (int e = 0; e < NF / 4; ++e) {
                     const float4 v = src[e];
@@ -336,12 +418,20 @@ __global__ __launch_bounds__(64 * K1A_MAXNW) void exact_lane_query_kernel(
                     bchunk[u] = imp ? t0 + c : bchunk[u];
                 }
             }
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of the next tile have landed
+                __syncthreads();                                   // everyone's have; everyone is done with this tile
+                K1A_STAMP(2 + ((t0 - j0) / TILE < 4 ? (t0 - j0) / TILE : 4));
+            }
         }
     }
     // ---- the workgroup's waves: packed keys through LDS --------------------------------------------
+    K1A_STAMP(7);
+    if constexpr (!kOwnKeys) __syncthreads();   // every wave is done with the last tile: its buffer becomes wkeys
 #pragma unroll
     for (int u = 0; u < K1A_QPL; ++u) wkeys[wave][u * 64 + lane] = make_key(best[u], index_base + bchunk[u]);
     __syncthreads();
+    K1A_STAMP(8);
     // Wave w finishes the queries of register slots u = w, w + nw, ... (< QPL): query blockIdx.x * QW +
     // u * 64 + lane, whose coordinates it holds in qv[u] (for the index recovery of write_final).
     if (mg.splits <= 1) {
@@ -370,11 +460,13 @@ __global__ __launch_bounds__(64 * K1A_MAXNW) void exact_lane_query_kernel(
             asm volatile("" ::"v"(old));   // returning atomic: waiting for its value = it has been performed
         }
     __syncthreads();                   // every atomic of the workgroup is done before the arrival is counted
+    K1A_STAMP(9);
     if (threadIdx.x == 0) {
         const int old = __hip_atomic_fetch_add(&mg.cnt[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = old == mg.splits - 1;
     }
     __syncthreads();
+    K1A_STAMP(10);
     if (!s_last) return;               // (workgroup-uniform)
 #pragma unroll
     for (int u = 0; u < K1A_QPL; ++u)
@@ -384,6 +476,7 @@ __global__ __launch_bounds__(64 * K1A_MAXNW) void exact_lane_query_kernel(
             write_final<K>(mg, keys, qi[u], v, qv[u], r, n, index_base);
         }
     if (threadIdx.x == 0) __hip_atomic_store(&mg.cnt[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    K1A_STAMP(11);
 }
 
 // geometry of a K1a launch
@@ -396,23 +489,25 @@ static K1aPlan k1a_plan(int m, int n)
     constexpr int CH = K1aChunk<K>::value;
     K1aPlan p;
     p.qtiles = divup(m, 64 * K1A_QPL);
-    // waves per workgroup: as many as it takes to reach the target wave count with ONE ref range per query
-    // tile, up to K1A_MAXNW (more waves per workgroup = fewer ref splits = fewer cross-workgroup merges),
-    // each wave with at least 4 chunks of work per LDS tile
-    int nw = divup(NNS_K1A_WAVES, p.qtiles);
-    if (nw > K1A_MAXNW) nw = K1A_MAXNW;
-    while (nw > 1 && (int64_t)nw * 4 * CH > n) nw >>= 1;
-    if (nw < 1) nw = 1;
+    // waves per workgroup: up to the target wave count with ONE ref range per query tile, each wave with at least
+    // 4 chunks of work per LDS tile; normally at most 8 (four workgroups per CU: one's head / tail / barrier waits are another's issue slots;
+    // 16-wave workgroups measured 4 % slower at C2 and 30 % slower on the 16-D scalar-ref form), 16 only where the
+    // finer cut would need more than 256 ref ranges per query tile (few queries: m = 100 x n = 100000)
+    int nw = 1, splits = 1;
+    for (int cap = NNS_K1A_NW; cap <= K1A_MAXNW; cap *= 2) {
+        nw = divup(NNS_K1A_WAVES, p.qtiles);
+        if (nw > cap) nw = cap;
+        while (nw > 1 && (int64_t)nw * 4 * CH > n) nw >>= 1;
+        if (nw < 1) nw = 1;
+        // ref splits: the rest of the way to the target, >= 16 refs per wave (small problems are launch-bound: a
+        // finer cut spreads 1024 x 4096 x 3 over 128 workgroups instead of 32: 12 -> 8 us; 512 x 8192 x 16: 46 -> 26)
+        splits = divup(NNS_K1A_WAVES, p.qtiles * nw);
+        const int max_splits = divup(n, (NNS_K1A_MIN_REFS_PER_WAVE) * nw);
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        if (splits <= 256) break;
+    }
     p.nw = nw;
-    // ref splits: the rest of the way to the target, >= 16 refs per wave (small problems are launch-bound: a
-    // finer cut spreads 1024 x 4096 x 3 over 128 workgroups instead of 32: 12 -> 8 us; 512 x 8192 x 16: 46 -> 26)
-    int splits = divup(NNS_K1A_WAVES, p.qtiles * nw);
-#ifndef NNS_K1A_MIN_REFS_PER_WAVE
-#define NNS_K1A_MIN_REFS_PER_WAVE 16
-#endif
-    const int max_splits = divup(n, (NNS_K1A_MIN_REFS_PER_WAVE) * nw);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
     int per = divup(n, splits);
     per = divup(per, CH) * CH;
@@ -455,9 +550,38 @@ static int launch_k1a(int m, int n, const float *q, const float *r, int64_t base
         }
     }
     mg.splits = p.splits;
-    hipLaunchKernelGGL(exact_lane_query_kernel<K>, dim3(p.qtiles, p.splits), dim3(64 * p.nw), 0, st,
-                       m, n, p.per, q, r, base, keys, mg);
+#ifdef NNS_K1A_STAMPS
+    static unsigned long long *stamps_dev = nullptr;
+    const size_t nwg = (size_t)p.qtiles * p.splits;
+    const bool stamp = getenv("NNS_K1A_STAMPS") != nullptr && nwg <= 65536;
+    if (stamp && !stamps_dev) NNS_HIP(hipMalloc(&stamps_dev, 65536 * 64 * sizeof(unsigned long long)));
+    mg.stamps = stamp ? stamps_dev : nullptr;
+    if (stamp) NNS_HIP(hipMemsetAsync(stamps_dev, 0, nwg * 64 * sizeof(unsigned long long), st));
+#endif
+    if (p.nw <= 8)
+        hipLaunchKernelGGL((exact_lane_query_kernel<K, 8>), dim3(p.qtiles, p.splits), dim3(64 * p.nw), 0, st,
+                           m, n, p.per, q, r, base, keys, mg);
+    else
+        hipLaunchKernelGGL((exact_lane_query_kernel<K, K1A_MAXNW>), dim3(p.qtiles, p.splits), dim3(64 * p.nw), 0, st,
+                           m, n, p.per, q, r, base, keys, mg);
     NNS_HIP(hipGetLastError());
+#ifdef NNS_K1A_STAMPS
+    if (stamp) {
+        NNS_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h(nwg * 64);
+        NNS_HIP(hipMemcpy(h.data(), stamps_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (size_t w = 0; w < nwg; ++w) t0 = std::min(t0, h[w * 64]);
+        fprintf(stderr, "k1a stamps: %d qtiles x %d splits x %d waves, per %d (x10 ns since the first entry; min / median / max over workgroups)\n", p.qtiles, p.splits, p.nw, p.per);
+        for (int i = 0; i < 48; ++i) {
+            std::vector<unsigned long long> v;
+            for (size_t w = 0; w < nwg; ++w) if (h[w * 64 + i]) v.push_back(h[w * 64 + i] - t0);
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "  stamp %2d: n %6zu  min %6llu  med %6llu  max %6llu\n", i, v.size(), v.front(), v[v.size() / 2], v.back());
+        }
+    }
+#endif
     return NNS_OK;
 }
 

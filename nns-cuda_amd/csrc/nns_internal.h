@@ -61,6 +61,33 @@ __device__ __forceinline__ float v0_step(float sum, float q, float r)
     return __fadd_rn(sum, __fmul_rn(diff, diff));
 }
 
+// LDS-DMA (global_load_lds_*): 64 lanes x {16, 4} bytes from per-lane global addresses to
+// LDS at M0 + lane * size, no VGPR destination.  Inline asm on purpose: through the
+// builtin, hipcc (ROCm 7.2) treats every later ds_read as possibly aliasing the
+// in-flight DMA and drains it with s_waitcnt vmcnt(0) right after the issue.  The asm
+// form is invisible to that pass; completion is tracked by OUR vmcnt waits + the slot
+// barrier.  M0 is compiler-reserved: saved and restored inside the same statement.
+__device__ __forceinline__ void dma16(const void *g, unsigned lds_byte)
+{
+    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);   // wave-uniform by construction: keep it scalar
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(lds_byte)
+                 : "memory");
+}
+__device__ __forceinline__ void dma4(const void *g, unsigned lds_byte)
+{
+    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(lds_byte)
+                 : "memory");
+}
+
 // ---- tile-image geometry (K2 output, K3 input) ---------------------------------
 // A "block" is 32 points.  Its image is [KT/8][2][32][4] floats:
 //   img[b][h][i][e] = value(point i, dim 8b + 4h + e)
