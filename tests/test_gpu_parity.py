@@ -1187,7 +1187,7 @@ def test_bench_rccl_path_world_size_one():
 
 def test_k1a_first_minimum_across_chunks_waves_and_splits(pkg, orc):
     """K1a keeps (distance, chunk start) through its merges and recovers the exact index once per query: exact
-    duplicates of the winner straddling every boundary it knows — chunk (8 refs), LDS tile (1360 refs at k = 3),
+    duplicates of the winner straddling every boundary it knows — chunk (8 refs), LDS tile (1280 refs at k = 3),
     wave round-robin, ref split — must still resolve to the LOWEST index; all-identical refs give index 0."""
     rng = np.random.default_rng(808)
     for k, n in ((3, 65536), (2, 40000), (16, 30000), (8, 5000)):
@@ -1196,7 +1196,7 @@ def test_k1a_first_minimum_across_chunks_waves_and_splits(pkg, orc):
         r = rng.random((n, k), dtype=np.float32) + np.float32(2.0)      # far from the queries
         hot = rng.random((1, k), dtype=np.float32)
         # the same nearest point at positions on both sides of every kind of boundary
-        for pos in (7, 8, 1359, 1360, 4095, 4096, 4097, n // 2 - 1, n // 2, n - 1):
+        for pos in (7, 8, 1279, 1280, 1359, 1360, 2559, 2560, 4095, 4096, 4097, n // 2 - 1, n // 2, n - 1):
             r[pos] = hot
         q[:350] = hot + rng.normal(0, 1e-3, (350, k)).astype(np.float32)
         want_idx, want_dist = orc.v0_search(q, r, threads=8)
@@ -1210,6 +1210,30 @@ def test_k1a_first_minimum_across_chunks_waves_and_splits(pkg, orc):
         assert (pkg.search(q[:350], r2, path="exact") == 8).all()
     same = np.tile(rng.random((1, 3), dtype=np.float32), (100000, 1))
     assert (pkg.search(rng.random((300, 3), dtype=np.float32), same) == 0).all()
+
+
+def test_k1a_lds_dma_staging_alignments_and_ragged_tiles(pkg, orc):
+    """K1a (k <= 4) stages its ref tiles and its queries by LDS-DMA: 16-byte pieces from a 16-byte-aligned source,
+    dword pieces otherwise and for the last partial piece, NaN / zero padding written by the lanes themselves.  Ref
+    and query arrays at every 4-byte misalignment, ragged ref counts (last tile / last chunk partial, one ref short
+    and one past a tile), ragged query counts — against the oracle, indices and distance bits."""
+    rng = np.random.default_rng(909)
+    dev = torch.device("cuda", 0)
+    for k in (1, 2, 3, 4):
+        for off_r, off_q, m, n in ((0, 0, 300, 5121), (1, 0, 129, 1280 * 3 + 7), (2, 1, 128, 1279), (3, 2, 5, 1281),
+                                   (1, 3, 1000, 70001), (0, 1, 64, 9), (5, 7, 257, 2560)):
+            rbig = rng.random((n + 8, k), dtype=np.float32)
+            qbig = rng.random((m + 8, k), dtype=np.float32)
+            r_d = torch.from_numpy(rbig).to(dev)[off_r:off_r + n]      # contiguous views at 4 k off_r bytes
+            q_d = torch.from_numpy(qbig).to(dev)[off_q:off_q + m]
+            assert r_d.is_contiguous() and q_d.is_contiguous()
+            want_idx, want_dist = orc.v0_search(qbig[off_q:off_q + m], rbig[off_r:off_r + n], threads=8)
+            ix = pkg.Index(r_d, path="exact")
+            idx, dist = ix.search(q_d, return_distances=True)
+            torch.cuda.synchronize()
+            assert np.array_equal(idx.cpu().numpy(), want_idx), (k, off_r, off_q, m, n)
+            assert np.array_equal(_bits(dist.cpu().numpy()), _bits(want_dist)), (k, off_r, off_q, m, n)
+            ix.close()
 
 
 def test_deep_tile_specials_and_whole_call_bf16_pipeline(pkg, orc):
