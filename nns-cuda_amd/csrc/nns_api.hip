@@ -47,9 +47,16 @@ static const int kTinyM = 64;
 static const unsigned kCreateNoSync = 1u << 30;
 // ... and a small problem in a dimensionality the lane-per-query exact kernel is instantiated for (8, 16)
 // is faster there than through the filter's fixed costs (K2 on both clouds, filter ramp, K5: ~55 us):
-// the reference driver's 16-D 1024 x 1024 sample (main.cu:44) takes 9 us instead of 57
-static const int64_t kSmallPairs = (int64_t)1 << 25;
-static bool small_exact(int k, int64_t m, int64_t n) { return (k == 8 || k == 16) && m >= kTinyM && m * n <= kSmallPairs; }
+// the reference driver's 16-D 1024 x 1024 sample (main.cu:44) takes 9 us instead of 57.  Crossovers measured with
+// the 8-wave K1a (tools/probe_crossover.py, profiles/r02_crossover.txt): 16-D 2^26 pairs 68 us either way (2^27:
+// 122 vs 95 us), 8-D 2^26 pairs 37 vs 64 us
+static bool small_exact(int k, int64_t m, int64_t n)
+{
+    if (m < kTinyM) return false;
+    if (k == 8) return m * n <= ((int64_t)1 << 27);
+    if (k == 16) return m * n <= ((int64_t)1 << 26);
+    return false;
+}
 // deepest dimensionality the MFMA filter tiles (bf16 operands; fp32 operands: 256)
 static const int kMaxFilterK = 1024;
 
