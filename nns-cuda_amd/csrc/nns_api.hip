@@ -749,6 +749,11 @@ struct Stager {
 
 Stager *g_stager = nullptr;
 std::mutex g_stager_mu;
+// small whole calls: one pinned scratch for inputs and outputs (search_host_small)
+constexpr size_t kSmallStageBytes = (size_t)2 << 20;
+void *g_small_pinned = nullptr;
+int g_small_device = -1;
+std::mutex g_small_mu;
 
 }  // namespace
 
@@ -762,6 +767,12 @@ void stager_release()
         g_stager->destroy();
         delete g_stager;
         g_stager = nullptr;
+    }
+    std::lock_guard<std::mutex> lk2(g_small_mu);
+    if (g_small_pinned) {
+        (void)hipHostFree(g_small_pinned);
+        g_small_pinned = nullptr;
+        g_small_device = -1;
     }
 }
 }  // namespace nns
@@ -907,6 +918,73 @@ int nns_selftest_lane_share(int tile16, const float *in64, float *out64)
     return rc;
 }
 
+// Small whole calls (the reference driver's m = 1 and 1024 x 1024 samples, main.cu:38-51: tens of KiB): what
+// main.cu:73-75 times is then the host round trips, not the search.  Inputs go through ONE pinned scratch and
+// ONE asynchronous upload into ONE pooled device block, the outputs come back through the same scratch, and the
+// host waits once (the plain path: two synchronous pageable uploads, a stream sync, one or two synchronous
+// downloads).  NNS_ERR_UNSUPPORTED: not applicable (too big, scratch busy or unavailable) -> the plain path.
+static int search_host_small(int k, int m, int n, const void *s_points, const void *r_points, int bf16,
+                             int *idx_out, float *dist_out, unsigned flags, int device)
+{
+    const size_t esz = bf16 ? sizeof(uint16_t) : sizeof(float);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t qb = (size_t)m * k * esz, rb = (size_t)n * k * esz;
+    const size_t off_r = up(qb), in_bytes = off_r + rb;
+    const size_t off_keys = up(in_bytes), off_idx = off_keys + up((size_t)m * sizeof(nns_key));
+    const size_t off_dist = off_idx + up((size_t)m * sizeof(int)), total = off_dist + up((size_t)m * sizeof(float));
+    const size_t out_bytes = (off_dist - off_idx) + (size_t)m * sizeof(float);
+    if (in_bytes + out_bytes + 512 > kSmallStageBytes || (flags & (NNS_REFS_SOA | NNS_PROFILE))) return NNS_ERR_UNSUPPORTED;
+    std::unique_lock<std::mutex> own(g_small_mu, std::try_to_lock);
+    if (!own.owns_lock()) return NNS_ERR_UNSUPPORTED;
+    if (g_small_pinned && g_small_device != device) {
+        (void)hipHostFree(g_small_pinned);
+        g_small_pinned = nullptr;
+    }
+    if (!g_small_pinned) {
+        if (hipHostMalloc(&g_small_pinned, kSmallStageBytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            g_small_pinned = nullptr;
+            return NNS_ERR_UNSUPPORTED;
+        }
+        g_small_device = device;
+    }
+    char *host = (char *)g_small_pinned, *host_out = host + up(in_bytes);
+    char *blk = nullptr;
+    if (pool_alloc(&blk, total) != hipSuccess) {
+        set_error("nns_search_f32: device allocation failed");
+        return NNS_ERR_NOMEM;
+    }
+    hipStream_t st = nullptr;
+    nns_index *ix = nullptr;
+    int rc = NNS_OK;
+    do {
+        memcpy(host, s_points, qb);
+        memcpy(host + off_r, r_points, rb);
+        if (hipMemcpyAsync(blk, host, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
+            set_error("nns_search_f32: H2D copy failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = NNS_ERR_HIP;
+            break;
+        }
+        // (no synchronising read-back at create: K5 checks NaN / INF / huge refs on the device)
+        if ((rc = index_create_impl(&ix, device, k, n, blk + off_r, bf16, 0, flags | kCreateNoSync, st)) != NNS_OK) break;
+        if ((rc = index_search_impl(ix, m, blk, bf16, (nns_key *)(blk + off_keys), st, (int *)(blk + off_idx),
+                                    (float *)(blk + off_dist))) != NNS_OK)
+            break;
+        if (hipMemcpyAsync(host_out, blk + off_idx, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            set_error("nns_search_f32: kernel execution or D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = NNS_ERR_HIP;
+            break;
+        }
+        memcpy(idx_out, host_out, (size_t)m * sizeof(int));
+        if (dist_out) memcpy(dist_out, host_out + (off_dist - off_idx), (size_t)m * sizeof(float));
+    } while (0);
+    if (ix) nns_index_destroy(ix);            // (synchronises)
+    else (void)hipDeviceSynchronize();        // the block goes back to the pool: nothing may still use it
+    pool_free(blk);
+    return rc;
+}
+
 static int search_host_impl(int k, int m, int n, const void *s_points, const void *r_points, int bf16,
                             int *idx_out, float *dist_out, int num_shards, unsigned flags, int device)
 {
@@ -923,6 +1001,10 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
     if (num_shards < 1) num_shards = 1;
     if (num_shards > n) num_shards = n;   // the reference clamps GPUs to n (core.cu:771-772)
     if ((flags & NNS_PATH_MASK) == NNS_PATH_AUTO && (m < kTinyM || (!bf16 && small_exact(k, m, n)))) flags |= NNS_PATH_EXACT;
+    if (num_shards == 1) {
+        const int src = search_host_small(k, m, n, s_points, r_points, bf16, idx_out, dist_out, flags, device);
+        if (src != NNS_ERR_UNSUPPORTED) return src;
+    }
     if (num_shards == 1 && pipeline_pays(k, m, n, bf16, flags, (size_t)n * k * esz)) {
         const int prc = search_host_pipelined(k, m, n, s_points, r_points, bf16, idx_out, dist_out, flags, device);
         if (prc != NNS_ERR_UNSUPPORTED) return prc;   // (UNSUPPORTED: ring busy / no pinned memory -> plain path)

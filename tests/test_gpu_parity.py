@@ -1236,6 +1236,39 @@ def test_k1a_lds_dma_staging_alignments_and_ragged_tiles(pkg, orc):
             ix.close()
 
 
+def test_small_whole_call_scratch_path_and_its_size_boundary(pkg, orc):
+    """Whole calls whose inputs + outputs fit the 2 MiB pinned scratch take one upload / one wait (search_host_small);
+    just above it the plain path runs.  Both sides of the boundary, fp32 and bf16, distances, NaN refs (the small
+    path builds its index without the synchronising read-back: K5's device-side check must catch them), and two
+    threads at once (the second finds the scratch busy and takes the plain path)."""
+    import threading
+    rng = np.random.default_rng(1234)
+    k = 16
+    for m, n in ((64, 32000), (64, 32500), (64, 33500), (1, 1024), (300, 20000)):   # 2 MiB = 32768 rows of 64 B
+        q = rng.random((m, k), dtype=np.float32)
+        r = rng.random((n, k), dtype=np.float32)
+        _check(pkg, orc, q, r, paths=("auto", "exact", "mfma"))
+    q = rng.random((200, 128), dtype=np.float32)
+    r = rng.random((3000, 128), dtype=np.float32)
+    r[5, 3] = np.nan
+    r[77, 0] = np.inf
+    r[100] = 3e18
+    _check(pkg, orc, q, r, paths=("auto", "mfma"))
+    qb = (rng.random((300, 256), dtype=np.float32)).astype(np.float32)
+    rb = (rng.random((1500, 256), dtype=np.float32)).astype(np.float32)
+    _check_bf16(pkg, orc, qb, rb)
+    want = orc.v0_search(q, r, threads=4)[0]
+    out = [None, None]
+
+    def work(i):
+        for _ in range(20):
+            out[i] = pkg.search(q, r)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert np.array_equal(out[0], want) and np.array_equal(out[1], want)
+
+
 def test_deep_tile_specials_and_whole_call_bf16_pipeline(pkg, orc):
     """The 1024-deep tile with NaN / INF refs and magnitudes that void the error bound (exact kernels must take
     over), and a bf16 whole call large enough for the pipelined upload."""
