@@ -778,14 +778,25 @@ void stager_release()
 }  // namespace nns
 }  // extern "C++"
 
+// (thresholds re-checked in round 2 with tools/probe_midcall.py: pipelining 12 .. 128 MiB uploads of problems with
+// 1024 .. 4096 queries, exact path included, is SLOWER — 64 MiB: 1.8 -> 2.7 ms — the runtime's own pageable copy
+// moves 43 GB/s, the staging threads 27; the knobs below are for such experiments)
 // when the pipelined path pays: MFMA-path problems whose upload is worth hiding behind >= tens of ms of search
 static bool pipeline_pays(int k, int64_t m, int64_t n, int bf16, unsigned flags, size_t rbytes)
 {
     if (flags & (NNS_REFS_SOA | NNS_PROFILE)) return false;
     const unsigned path = flags & NNS_PATH_MASK;
+#ifndef NNS_PIPE_MIN_MB
+#define NNS_PIPE_MIN_MB 128
+#endif
+#ifndef NNS_PIPE_MIN_M
+#define NNS_PIPE_MIN_M 8192
+#endif
+#ifndef NNS_PIPE_EXACT
     if (path == NNS_PATH_EXACT) return false;
     if (k < (bf16 ? 32 : 8) || k > kMaxFilterK) return false;
-    return rbytes >= ((size_t)128 << 20) && n >= (1 << 18) && m >= 8192;
+#endif
+    return rbytes >= ((size_t)NNS_PIPE_MIN_MB << 20) && n >= (1 << 18) && m >= NNS_PIPE_MIN_M;
 }
 
 static int search_host_pipelined(int k, int m, int n, const void *s_points, const void *r_points, int bf16,
