@@ -10,9 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
-#include <atomic>
 #include <mutex>
-#include <thread>
 #include <vector>
 
 #include "nns_internal.h"
@@ -672,102 +670,20 @@ int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const fl
     return rc;
 }
 
-// ---- pipelined upload of the whole-call entry points ---------------------------------------------------
-// The reference times alloc + H2D + kernels + D2H (main.cu:73-75).  A plain hipMemcpy of pageable memory
-// does not overlap the filter (its staging blits wait for the resident workgroups: measured), so large
-// MFMA-path calls upload through a ring of pinned staging buffers — filled by a few host threads, drained
-// by asynchronous (SDMA) copies on a copy stream — while the GPU already searches the first ref chunks.
-// Chunks grow geometrically (1/16, 1/8, 1/4, rest): the exposed upload is the queries + the small first
-// chunk, and most of the work runs on long ref streams.  Chunk results merge with nns_keys_min: the answer
-// is the unsharded one bit for bit.
+// ---- host-side state of the whole-call entry points ---------------------------------------------------------
 namespace {
-
-struct Stager {
-    static constexpr int NB = 4;
-    static constexpr size_t BUF = (size_t)16 << 20;
-    void *pinned[NB] = {};
-    hipEvent_t done[NB] = {};
-    bool used[NB] = {};
-    hipStream_t copy = nullptr;
-    int threads = 4;
-    int device = 0;
-    bool ok = false;
-
-    int init()
-    {
-        for (int b = 0; b < NB; ++b)
-            if (hipHostMalloc(&pinned[b], BUF, hipHostMallocDefault) != hipSuccess ||
-                hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess)
-                return NNS_ERR_NOMEM;
-        if (hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) return NNS_ERR_HIP;
-        const unsigned hw = std::thread::hardware_concurrency();
-        threads = hw >= 8 ? NB : (hw >= 4 ? 2 : 1);   // staging workers (<= NB: one pinned buffer each)
-        ok = true;
-        return NNS_OK;
-    }
-    void destroy()
-    {
-        if (copy) {
-            (void)hipStreamSynchronize(copy);
-            (void)hipStreamDestroy(copy);
-        }
-        for (int b = 0; b < NB; ++b) {
-            if (done[b]) (void)hipEventDestroy(done[b]);
-            if (pinned[b]) (void)hipHostFree(pinned[b]);
-        }
-    }
-    // host -> device, asynchronous on the copy stream (returns once the last piece is STAGED and its copy
-    // ISSUED, not landed).  Pieces of BUF bytes go round-robin to up to NB staging workers, each with its own
-    // pinned buffer: memcpy into it (once the buffer's previous copy has drained), issue the async copy, record
-    // the buffer's event.  The order in which the pieces' copies reach the stream does not matter: the caller
-    // records its "landed" event behind all of them.
-    int upload(void *dst, const void *src, size_t bytes)
-    {
-        const size_t npieces = (bytes + BUF - 1) / BUF;
-        const int nt = (int)(npieces < (size_t)threads ? npieces : (size_t)threads);
-        std::atomic<int> failed{0};
-        auto work = [&](int t) {
-            (void)hipSetDevice(device);
-            for (size_t p = (size_t)t; p < npieces && !failed.load(std::memory_order_relaxed); p += (size_t)nt) {
-                const size_t off = p * BUF, piece = bytes - off < BUF ? bytes - off : BUF;
-                const int b = t;                     // worker t owns buffer t
-                if (used[b] && hipEventSynchronize(done[b]) != hipSuccess) failed = 1;
-                memcpy(pinned[b], (const char *)src + off, piece);
-                if (hipMemcpyAsync((char *)dst + off, pinned[b], piece, hipMemcpyHostToDevice, copy) != hipSuccess ||
-                    hipEventRecord(done[b], copy) != hipSuccess)
-                    failed = 1;
-                used[b] = true;
-            }
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto &t : th) t.join();
-        return failed.load() ? NNS_ERR_HIP : NNS_OK;
-    }
-};
-
-Stager *g_stager = nullptr;
-std::mutex g_stager_mu;
 // small whole calls: one pinned scratch for inputs and outputs (search_host_small)
 constexpr size_t kSmallStageBytes = (size_t)2 << 20;
 void *g_small_pinned = nullptr;
 int g_small_device = -1;
 std::mutex g_small_mu;
-
 }  // namespace
 
 extern "C++" {
 namespace nns {
-// nns_shutdown: give the pinned staging ring back
+// nns_shutdown: give the pinned scratch back
 void stager_release()
 {
-    std::lock_guard<std::mutex> lk(g_stager_mu);
-    if (g_stager) {
-        g_stager->destroy();
-        delete g_stager;
-        g_stager = nullptr;
-    }
     std::lock_guard<std::mutex> lk2(g_small_mu);
     if (g_small_pinned) {
         (void)hipHostFree(g_small_pinned);
@@ -777,130 +693,6 @@ void stager_release()
 }
 }  // namespace nns
 }  // extern "C++"
-
-// (thresholds re-checked in round 2 with tools/probe_midcall.py: pipelining 12 .. 128 MiB uploads of problems with
-// 1024 .. 4096 queries, exact path included, is SLOWER — 64 MiB: 1.8 -> 2.7 ms — the runtime's own pageable copy
-// moves 43 GB/s, the staging threads 27; the knobs below are for such experiments)
-// when the pipelined path pays: MFMA-path problems whose upload is worth hiding behind >= tens of ms of search
-static bool pipeline_pays(int k, int64_t m, int64_t n, int bf16, unsigned flags, size_t rbytes)
-{
-    if (flags & (NNS_REFS_SOA | NNS_PROFILE)) return false;
-    const unsigned path = flags & NNS_PATH_MASK;
-#ifndef NNS_PIPE_MIN_MB
-#define NNS_PIPE_MIN_MB 128
-#endif
-#ifndef NNS_PIPE_MIN_M
-#define NNS_PIPE_MIN_M 8192
-#endif
-#ifndef NNS_PIPE_EXACT
-    if (path == NNS_PATH_EXACT) return false;
-    if (k < (bf16 ? 32 : 8) || k > kMaxFilterK) return false;
-#endif
-    return rbytes >= ((size_t)NNS_PIPE_MIN_MB << 20) && n >= (1 << 18) && m >= NNS_PIPE_MIN_M;
-}
-
-static int search_host_pipelined(int k, int m, int n, const void *s_points, const void *r_points, int bf16,
-                                 int *idx_out, float *dist_out, unsigned flags, int device)
-{
-    const size_t esz = bf16 ? sizeof(uint16_t) : sizeof(float);
-    const size_t qb = (size_t)m * k * esz, rb = (size_t)n * k * esz;
-    char *q_d = nullptr, *r_d = nullptr;
-    float *dist_d = nullptr;
-    nns_key *keys = nullptr, *keys_tmp = nullptr;
-    int *idx_d = nullptr;
-    hipStream_t st = nullptr;          // compute: the default stream (orders with everything else of the call)
-    hipEvent_t landed = nullptr;
-    std::vector<nns_index *> shards;
-    // the pinned ring is kept for the life of the process (pinning 64 MiB costs milliseconds): one pipelined
-    // call at a time owns it, a concurrent caller takes the plain path
-    std::unique_lock<std::mutex> own(g_stager_mu, std::try_to_lock);
-    if (!own.owns_lock()) return NNS_ERR_UNSUPPORTED;
-    if (!g_stager || g_stager->device != device) {
-        if (g_stager) {
-            g_stager->destroy();
-            delete g_stager;
-            g_stager = nullptr;
-        }
-        Stager *ns = new (std::nothrow) Stager();
-        if (!ns || ns->init() != NNS_OK) {
-            if (ns) {
-                ns->destroy();
-                delete ns;
-            }
-            (void)hipGetLastError();
-            return NNS_ERR_UNSUPPORTED;    // no pinned memory: the plain path still works
-        }
-        ns->device = device;
-        g_stager = ns;
-    }
-    Stager &sg = *g_stager;
-    for (int b = 0; b < Stager::NB; ++b) sg.used[b] = false;
-    int rc = NNS_OK;
-    do {
-        if (hipEventCreateWithFlags(&landed, hipEventDisableTiming) != hipSuccess) {
-            rc = NNS_ERR_HIP;
-            break;
-        }
-        if (pool_alloc(&q_d, qb) != hipSuccess || pool_alloc(&r_d, rb) != hipSuccess ||
-            pool_alloc(&keys, (size_t)m * sizeof(nns_key)) != hipSuccess ||
-            pool_alloc(&keys_tmp, (size_t)m * sizeof(nns_key)) != hipSuccess ||
-            pool_alloc(&idx_d, (size_t)m * sizeof(int)) != hipSuccess ||
-            pool_alloc(&dist_d, (size_t)m * sizeof(float)) != hipSuccess) {
-            set_error("nns_search: device allocation failed");
-            rc = NNS_ERR_NOMEM;
-            break;
-        }
-        if ((rc = sg.upload(q_d, s_points, qb)) != NNS_OK) break;
-        // ref chunks: 1/16, 1/8, 1/4, the rest (multiples of 512 refs: whole ring slots at every tile depth)
-        int bounds[5] = {0, 0, 0, 0, n};
-        {
-            const int64_t unit = 512;
-            bounds[1] = (int)(((int64_t)n / 16 + unit - 1) / unit * unit);
-            bounds[2] = (int)(((int64_t)n * 3 / 16 + unit - 1) / unit * unit);
-            bounds[3] = (int)(((int64_t)n * 7 / 16 + unit - 1) / unit * unit);
-        }
-        bool first = true;
-        for (int c = 0; c < 4 && rc == NNS_OK; ++c) {
-            const int beg = bounds[c], cnt = bounds[c + 1] - bounds[c];
-            if (cnt <= 0) continue;
-            if ((rc = sg.upload(r_d + (size_t)beg * k * esz, (const char *)r_points + (size_t)beg * k * esz,
-                                (size_t)cnt * k * esz)) != NNS_OK)
-                break;
-            // the chunk (and, for the first one, the queries) has landed before its search starts
-            if (hipEventRecord(landed, sg.copy) != hipSuccess || hipStreamWaitEvent(st, landed, 0) != hipSuccess) {
-                rc = NNS_ERR_HIP;
-                break;
-            }
-            nns_index *ix = nullptr;
-            rc = index_create_impl(&ix, device, k, cnt, r_d + (size_t)beg * k * esz, bf16, beg, flags | kCreateNoSync, st);
-            if (rc != NNS_OK) break;
-            shards.push_back(ix);
-            rc = index_search_impl(ix, m, q_d, bf16, first ? keys : keys_tmp, st);
-            if (rc == NNS_OK && !first) rc = nns_keys_min(keys, keys_tmp, m, st);
-            first = false;
-        }
-        if (rc != NNS_OK) break;
-        rc = nns_keys_unpack(keys, m, idx_d, dist_d, st);
-        if (rc != NNS_OK) break;
-        if (hipMemcpy(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
-            (dist_out && hipMemcpy(dist_out, dist_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
-            set_error("nns_search: kernel execution or D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
-            rc = NNS_ERR_HIP;
-        }
-    } while (0);
-    if (rc == NNS_ERR_HIP && !*nns_last_error()) set_error("nns_search (pipelined): %s", hipGetErrorString(hipGetLastError()));
-    (void)hipDeviceSynchronize();   // the blocks go back to the pool: nothing may still use them
-    for (nns_index *ix : shards) nns_index_destroy(ix);
-    (void)hipStreamSynchronize(sg.copy);
-    if (landed) (void)hipEventDestroy(landed);
-    pool_free(q_d);
-    pool_free(r_d);
-    pool_free(keys);
-    pool_free(keys_tmp);
-    pool_free(idx_d);
-    pool_free(dist_d);
-    return rc;
-}
 
 int nns_plan_filter(int k, int m, int n, int bf16_points, unsigned flags, int *out, int out_len)
 {
@@ -996,6 +788,119 @@ static int search_host_small(int k, int m, int n, const void *s_points, const vo
     return rc;
 }
 
+// ---- overlapped upload of the whole-call entry points ----------------------------------------------------
+// The reference times alloc + H2D + kernels + D2H (main.cu:73-75).  Whole calls whose search is worth hiding an
+// upload behind send the refs up in four growing chunks (1/8, 1/4, 5/16, 5/16) with the runtime's own synchronous
+// pageable copy, and search each chunk on a NON-BLOCKING stream as soon as its copy has returned: the next chunk's
+// copy runs beside that search (on the legacy default stream it does not — round 1 read that as "pageable copies
+// do not overlap resident workgroups" and built a ring of pinned buffers filled by host threads; on a non-blocking
+// stream the plain copy overlaps just as well and moves 43 GB/s against the ring's 27: C3 122.3 ms either way,
+// 4096 x 524288 x 128 9.4 -> 6.7 ms, profiles/r02_midcall.txt; the ring is gone).  Chunk results merge with
+// nns_keys_min: the answer is the unsharded one bit for bit.  No threads, no pinned memory.
+//
+// When it pays: four shards cost ~0.25 ms of launches, so the search must be worth >= 0.5 ms (estimated from the
+// measured rates: fp32 MFMA 140 TF, bf16-operand tiles 1.4 PF, exact VALU kernels 45 Tflop/s at 3k flop per pair).
+#ifndef NNS_CHUNK_MIN_MB
+#define NNS_CHUNK_MIN_MB 8
+#endif
+static bool chunked_pays(int k, int64_t m, int64_t n, int bf16, unsigned flags, size_t rbytes)
+{
+    if (flags & (NNS_REFS_SOA | NNS_PROFILE)) return false;
+    if (rbytes < ((size_t)NNS_CHUNK_MIN_MB << 20) || n < 4096 || m < kTinyM) return false;
+    const unsigned path = flags & NNS_PATH_MASK;
+    const bool exact = path == NNS_PATH_EXACT || k < (bf16 ? 32 : 8) || k > kMaxFilterK;
+    double est_s;
+    if (exact) {
+        est_s = 3.0 * k * (double)m * (double)n / 45e12;
+    } else {
+        int kt = bf16 ? 128 : 16;
+        while (kt < k) kt *= 2;
+        const bool bf16_ops = bf16 || k > 256 || (flags & NNS_FILTER_BF16);
+        est_s = 2.0 * kt * (double)m * (double)n / (bf16_ops ? 1.4e15 : 140e12);
+    }
+    return est_s >= 0.5e-3;
+}
+
+static int search_host_chunked(int k, int m, int n, const void *s_points, const void *r_points, int bf16,
+                               int *idx_out, float *dist_out, unsigned flags, int device)
+{
+    const size_t esz = bf16 ? sizeof(uint16_t) : sizeof(float);
+    const size_t qb = (size_t)m * k * esz, rb = (size_t)n * k * esz;
+    char *q_d = nullptr, *r_d = nullptr;
+    float *dist_d = nullptr;
+    nns_key *keys = nullptr, *keys_tmp = nullptr;
+    int *idx_d = nullptr;
+    hipStream_t st = nullptr;
+    std::vector<nns_index *> shards;
+    int rc = NNS_OK;
+    do {
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            return NNS_ERR_UNSUPPORTED;
+        }
+        if (pool_alloc(&q_d, qb) != hipSuccess || pool_alloc(&r_d, rb) != hipSuccess ||
+            pool_alloc(&keys, (size_t)m * sizeof(nns_key)) != hipSuccess ||
+            pool_alloc(&keys_tmp, (size_t)m * sizeof(nns_key)) != hipSuccess ||
+            pool_alloc(&idx_d, (size_t)m * sizeof(int)) != hipSuccess ||
+            pool_alloc(&dist_d, (size_t)m * sizeof(float)) != hipSuccess) {
+            set_error("nns_search: device allocation failed");
+            rc = NNS_ERR_NOMEM;
+            break;
+        }
+        if (hipMemcpy(q_d, s_points, qb, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = NNS_ERR_HIP;
+            break;
+        }
+        // chunks of 1/8, 1/4, 5/16, 5/16 of the refs (multiples of 512: whole ring slots at every tile depth)
+        int bounds[5] = {0, 0, 0, 0, n};
+        {
+            const int64_t unit = 512;
+            bounds[1] = (int)(((int64_t)n * 2 / 16 + unit - 1) / unit * unit);
+            bounds[2] = (int)(((int64_t)n * 6 / 16 + unit - 1) / unit * unit);
+            bounds[3] = (int)(((int64_t)n * 11 / 16 + unit - 1) / unit * unit);
+            for (int c = 1; c < 4; ++c)
+                if (bounds[c] > n) bounds[c] = n;
+        }
+        bool first = true;
+        for (int c = 0; c < 4 && rc == NNS_OK; ++c) {
+            const int beg = bounds[c], cnt = bounds[c + 1] - bounds[c];
+            if (cnt <= 0) continue;
+            // synchronous: the chunk is on the device when this returns; the previous chunk's search keeps running
+            if (hipMemcpy(r_d + (size_t)beg * k * esz, (const char *)r_points + (size_t)beg * k * esz, (size_t)cnt * k * esz,
+                          hipMemcpyHostToDevice) != hipSuccess) {
+                rc = NNS_ERR_HIP;
+                break;
+            }
+            nns_index *ix = nullptr;
+            rc = index_create_impl(&ix, device, k, cnt, r_d + (size_t)beg * k * esz, bf16, beg, flags | kCreateNoSync, st);
+            if (rc != NNS_OK) break;
+            shards.push_back(ix);
+            rc = index_search_impl(ix, m, q_d, bf16, first ? keys : keys_tmp, st);
+            if (rc == NNS_OK && !first) rc = nns_keys_min(keys, keys_tmp, m, st);
+            first = false;
+        }
+        if (rc != NNS_OK) break;
+        rc = nns_keys_unpack(keys, m, idx_d, dist_d, st);
+        if (rc != NNS_OK) break;
+        if (hipStreamSynchronize(st) != hipSuccess ||
+            hipMemcpy(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+            (dist_out && hipMemcpy(dist_out, dist_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
+            rc = NNS_ERR_HIP;
+        }
+    } while (0);
+    if (rc == NNS_ERR_HIP) set_error("nns_search (chunked upload): %s", hipGetErrorString(hipGetLastError()));
+    (void)hipDeviceSynchronize();   // the blocks go back to the pool: nothing may still use them
+    for (nns_index *ix : shards) nns_index_destroy(ix);
+    if (st) (void)hipStreamDestroy(st);
+    pool_free(q_d);
+    pool_free(r_d);
+    pool_free(keys);
+    pool_free(keys_tmp);
+    pool_free(idx_d);
+    pool_free(dist_d);
+    return rc;
+}
+
 static int search_host_impl(int k, int m, int n, const void *s_points, const void *r_points, int bf16,
                             int *idx_out, float *dist_out, int num_shards, unsigned flags, int device)
 {
@@ -1016,9 +921,9 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
         const int src = search_host_small(k, m, n, s_points, r_points, bf16, idx_out, dist_out, flags, device);
         if (src != NNS_ERR_UNSUPPORTED) return src;
     }
-    if (num_shards == 1 && pipeline_pays(k, m, n, bf16, flags, (size_t)n * k * esz)) {
-        const int prc = search_host_pipelined(k, m, n, s_points, r_points, bf16, idx_out, dist_out, flags, device);
-        if (prc != NNS_ERR_UNSUPPORTED) return prc;   // (UNSUPPORTED: ring busy / no pinned memory -> plain path)
+    if (num_shards == 1 && chunked_pays(k, m, n, bf16, flags, (size_t)n * k * esz)) {
+        const int crc = search_host_chunked(k, m, n, s_points, r_points, bf16, idx_out, dist_out, flags, device);
+        if (crc != NNS_ERR_UNSUPPORTED) return crc;   // (UNSUPPORTED: no stream -> plain path)
     }
 
     char *q_d = nullptr, *r_d = nullptr, *r_t = nullptr;

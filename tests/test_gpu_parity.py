@@ -1084,10 +1084,10 @@ def test_search_indices_fused_unpack_and_k1a_rearm(pkg, orc):
 
 @pytest.mark.timeout(600)
 def test_whole_call_pipelined_upload(pkg, orc):
-    """Large MFMA-path whole calls upload through the pinned staging ring while the first ref chunks are
-    already being searched (chunks of 1/16, 1/8, 1/4 and the rest, merged with the packed-key min): the
-    answer must be the unsharded V0 answer bit for bit — with exact cross-chunk ties, and with a NaN in a
-    late chunk (found by K5's device-side check, since the pipelined build never synchronises)."""
+    """Whole calls worth it upload their refs in four chunks (1/8, 1/4, 5/16, 5/16) and search each chunk on a
+    non-blocking stream while the next one is copied (merged with the packed-key min): the answer must be the
+    unsharded V0 answer bit for bit — with exact cross-chunk ties, and with a NaN in a late chunk (found by K5's
+    device-side check, since the chunk indexes are built without the synchronising read-back)."""
     m, n, k = 8192, 262144 + 777, 128
     q = orc.rng_uniform(m * k, 91, 0).reshape(m, k)
     r = orc.rng_uniform(n * k, 91, m * k).reshape(n, k)
@@ -1095,18 +1095,18 @@ def test_whole_call_pipelined_upload(pkg, orc):
     q[0] = r[3]
     q[1] = r[n - 9]                      # exact hit in the last chunk
     want_idx, want_dist = orc.v0_search(q, r, threads=16)
-    for rep in range(2):                 # second call: the cached staging ring and pooled workspaces
+    for rep in range(2):                 # second call: pooled workspaces
         idx, dist = pkg.search(q, r, return_distances=True)
         assert np.array_equal(idx, want_idx), rep
         assert np.array_equal(_bits(dist), _bits(want_dist))
     assert np.array_equal(pkg.cudaCall(k, m, n, q, r), want_idx)
-    assert np.array_equal(pkg.search(q, r, shards=3), want_idx)     # the plain (non-pipelined) path agrees
+    assert np.array_equal(pkg.search(q, r, shards=3), want_idx)     # the plain (synchronous) path agrees
     r2 = r.copy()
     r2[200000, 7] = np.nan
     with np.errstate(all="ignore"):
         w2 = orc.v0_search(q, r2, threads=16)[0]
     assert np.array_equal(pkg.search(q, r2), w2)
-    pkg.shutdown()                       # releases the pinned ring; the next call rebuilds it
+    pkg.shutdown()                       # releases communicators / scratch; the next call rebuilds what it needs
     assert np.array_equal(pkg.search(q, r), want_idx)
 
 
@@ -1284,7 +1284,7 @@ def test_deep_tile_specials_and_whole_call_bf16_pipeline(pkg, orc):
         _check_bf16(pkg, orc, q, r, paths=("auto", "mfma"), shards=(1, 2))
         big = (rng.random((m, k), dtype=np.float32) * np.float32(3e18), rng.random((n, k), dtype=np.float32) * np.float32(3e18))
         _check(pkg, orc, big[0], big[1], paths=("auto",), shards=(1,))
-    m, n, k = 8192, 262144, 256                                       # 128 MiB of bf16 refs: pipelined
+    m, n, k = 8192, 262144, 256                                       # 128 MiB of bf16 refs: chunked upload
     q = orc.round_bf16(orc.rng_uniform(m * k, 92, 0).reshape(m, k))
     r = orc.round_bf16(orc.rng_uniform(n * k, 92, m * k).reshape(n, k))
     r[n - 3] = r[5]
