@@ -1236,6 +1236,32 @@ def test_k1a_lds_dma_staging_alignments_and_ragged_tiles(pkg, orc):
             ix.close()
 
 
+def test_whole_call_chunked_upload_exact_path(pkg, orc):
+    """The chunked, overlapped upload also serves exact-path whole calls worth >= 0.5 ms (3-D, 4096 x 700001: 8.4 MB of
+    refs in four chunks through K1a, merged with the packed-key min): cross-chunk exact ties resolve to the lowest
+    index, a ragged last chunk, distances bit-equal; and a 16-D problem just above the small-problem rule (MFMA path,
+    16-deep tile, chunked)."""
+    m, n, k = 4096, 700001, 3
+    q = orc.rng_uniform(m * k, 17, 0).reshape(m, k)
+    r = orc.rng_uniform(n * k, 17, m * k).reshape(n, k)
+    r[n - 2] = r[11]                     # the same point in the first and in the last chunk
+    q[5] = r[11]
+    q[6] = r[n - 1]
+    want_idx, want_dist = orc.v0_search(q, r, threads=16)
+    assert want_idx[5] == 11 and want_idx[6] == n - 1
+    idx, dist = pkg.search(q, r, return_distances=True)
+    assert np.array_equal(idx, want_idx)
+    assert np.array_equal(_bits(dist), _bits(want_dist))
+    m, n, k = 4096, 40000, 16            # 1.6e8 pairs > 2^26: MFMA path; est. search < 0.5 ms -> plain upload
+    q = orc.rng_uniform(m * k, 18, 0).reshape(m, k)
+    r = orc.rng_uniform(n * k, 18, m * k).reshape(n, k)
+    assert np.array_equal(pkg.search(q, r), orc.v0_search(q, r, threads=16)[0])
+    m, n, k = 4096, 600011, 16           # 38 MB of refs, est. search 0.56 ms: chunked, 16-deep tile
+    q = orc.rng_uniform(m * k, 19, 0).reshape(m, k)
+    r = orc.rng_uniform(n * k, 19, m * k).reshape(n, k)
+    assert np.array_equal(pkg.search(q, r), orc.v0_search(q, r, threads=16)[0])
+
+
 def test_small_whole_call_scratch_path_and_its_size_boundary(pkg, orc):
     """Whole calls whose inputs + outputs fit the 2 MiB pinned scratch take one upload / one wait (search_host_small);
     just above it the plain path runs.  Both sides of the boundary, fp32 and bf16, distances, NaN refs (the small
