@@ -127,10 +127,12 @@ __device__ __forceinline__ nns_key wave_min_key(nns_key v)
 // K1a: lane = query, wave-uniform refs
 // ---------------------------------------------------------------------------
 // K1a geometry: a lane holds QPL queries in registers; a workgroup of NW waves (all NW waves hold the SAME
-// 64 x QPL queries) walks its ref range in chunks of CH refs, the waves round-robin.  K <= 4: the workgroup
-// stages a tile of the range in LDS (coalesced) and a chunk is read by BROADCAST ds_read_b128 (all lanes, same
-// address: one LDS access, no bank conflict).  K >= 8: a chunk is 32 floats — the wave fetches it itself with
-// scalar loads (wave-uniform address) and the refs feed the VALU as SGPR operands.
+// 64 x QPL queries) walks its ref range in chunks of CH refs, the waves round-robin.  K <= 4: the workgroup's
+// queries and double-buffered tiles of the range come into LDS by LDS-DMA (the next tile in flight while the
+// current one is walked) and a chunk is read by BROADCAST ds_read_b128 (all lanes, same address: one LDS access,
+// no bank conflict).  K >= 8: a chunk is 32 floats — the wave fetches it itself with scalar loads (wave-uniform
+// address) and the refs feed the VALU as SGPR operands.  Workgroups are 8 waves (four per CU) unless the problem
+// has so few queries that the cut would need more than 256 ref ranges (k1a_plan).
 //
 // The inner loop is branch-free: per pair the 3K - 1 V0 operations (the first add of the chain is
 // 0 + x = x, exact), per chunk a min tree and TWO conditional moves — the lane's best distance and the
