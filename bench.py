@@ -478,7 +478,25 @@ def main():
                 ent["note"] = ("opt-in extra, not the headline: same inputs as c3, filter on bf16 operands "
                                "(wider tau, more candidates), answers re-ranked with V0's fp32 arithmetic")
                 ent["same_indices_as_c3"] = bool(torch.equal(idx2, idx_c3))
-            elif orc is not None:
+            if name in ("c1", "c2"):
+                # launch-bound shapes: the same 200 back-to-back searches WITHOUT the per-launch HIP events of the
+                # profiled loop above (an event record between two launches keeps the next kernel's head from
+                # overlapping the previous one's tail) — SURVEY 8(d) defines C2's time this way
+                ix_np = pkg.Index(r2, path="auto", profile=False)
+                idx_np = torch.empty(o["config"]["m"], dtype=torch.int32, device=dev)
+                for _ in range(wu_):
+                    ix_np.search_indices(q2, keys2, idx_np)
+                torch.cuda.synchronize()
+                t_np = time.perf_counter()
+                for _ in range(st_):
+                    ix_np.search_indices(q2, keys2, idx_np)
+                torch.cuda.synchronize()
+                dt_np = (time.perf_counter() - t_np) / st_
+                ent["unprofiled"] = {"ms_per_step": dt_np * 1e3, "value": o["config"]["m"] * float(o["config"]["n"]) / dt_np,
+                                     "unit": "pairs/s", "same_indices": bool(torch.equal(idx_np, idx2)),
+                                     "note": "no HIP events between launches; not the line's value"}
+                ix_np.close()
+            if name != "c3x" and orc is not None:
                 full = name == "c1"            # C1 is the reference's CPU-runnable case: V0 over the whole problem
                 qs, is_ = baseline_sample(q2, idx2)
                 ent["cpu_baseline"] = cpu_baseline(orc, qs, r2.float().cpu().numpy(), is_, target_s=4.0, full=full)
