@@ -117,6 +117,40 @@ struct AccSet16 {
     }
 };
 
+// sixteen 16x16 tiles [ref tile rt][query tile qt]: 128 queries per wave (the one-wave-per-SIMD form of OpBF16)
+struct AccSet16W {
+    f32x4 a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+    template <int RT, int QT>
+    __device__ __forceinline__ f32x4 &at()
+    {
+        static_assert(RT >= 0 && RT < 2 && QT >= 0 && QT < 8, "2 ref tiles x 8 query tiles");
+        if constexpr (RT == 0) {
+            if constexpr (QT == 0) return a0;
+            else if constexpr (QT == 1) return a1;
+            else if constexpr (QT == 2) return a2;
+            else if constexpr (QT == 3) return a3;
+            else if constexpr (QT == 4) return a4;
+            else if constexpr (QT == 5) return a5;
+            else if constexpr (QT == 6) return a6;
+            else return a7;
+        } else {
+            if constexpr (QT == 0) return b0;
+            else if constexpr (QT == 1) return b1;
+            else if constexpr (QT == 2) return b2;
+            else if constexpr (QT == 3) return b3;
+            else if constexpr (QT == 4) return b4;
+            else if constexpr (QT == 5) return b5;
+            else if constexpr (QT == 6) return b6;
+            else return b7;
+        }
+    }
+    template <int RT, int QT>
+    __device__ __forceinline__ const f32x4 &at() const
+    {
+        return const_cast<AccSet16W *>(this)->template at<RT, QT>();
+    }
+};
+
 // Timing diagnostics only (results are wrong): build with -DNNS_DIAG -DNNS_FILTER_ABLATE=<bits>
 //   1 no ring sync (wait + barrier), 2 no epilogue, 16 no DMA issue.  The product build (no NNS_DIAG)
 // has none of the diagnostic switches: no ablation, no NNS_FILTER_CLOCK / NNS_DIAG_FILTER_ONLY
@@ -206,15 +240,15 @@ using OpF32K256 = OpF32T<32, 1>;
 // not hide it, measured), which cost 7-9 % of this kernel.  Two v_min per MFMA gap fit the 8
 // issue cycles a 16x16x32 leaves free, so the reduction of tile rt's finished scores is spread
 // over k-step 1 of tile 1 - rt, and the threshold test + (rare) slow path follow at k-step 2.
-template <int SPB_, int NW_ = NNS_F_NW_BF16, bool ASM_ = true>
+template <int SPB_, int NW_ = NNS_F_NW_BF16, bool ASM_ = true, int QB_ = 2>
 struct OpBF16T {
     static constexpr int kSPB = SPB_;         // 16: KT = 256 (8 k-steps per 16-ref tile); 8: KT = 128 (4 k-steps); 32: KT = 512
     static constexpr bool kAsmMfma = ASM_;    // false: compiler builtins (the 512-deep form: operands beyond the 256 ArchVGPRs an asm "v" can name)
     static constexpr bool kTile16 = true;
     static constexpr bool kLag = false;       // lock-step SIMD partners (lagging them: +1..4 % time on C5)
     static constexpr bool kTauInRegs = false; // 222-234 VGPRs: the four states' constants live in LDS (read on the slow path)
-    using Acc = AccSet16;
-    static constexpr int kQB = 2;             // 64 queries per wave = 4 query tiles
+    using Acc = std::conditional_t<QB_ == 4, AccSet16W, AccSet16>;
+    static constexpr int kQB = QB_;           // 2: 64 queries per wave = 4 query tiles; 4: 128 queries = 8 tiles (one wave per SIMD)
     static constexpr int kNW = NW_;
 #ifndef NNS_F_PF_BF16
 #define NNS_F_PF_BF16 2
@@ -228,7 +262,11 @@ struct OpBF16T {
     // the epilogue's fences (mma16_fence_lo / _hi).
     __device__ static __forceinline__ void mma16(const float4 &a, const float4 &b, f32x4 &acc)
     {
-        if constexpr (ASM_)
+        if constexpr (ASM_ && QB_ == 4)   // the wave's 256 query-operand registers are the AGPR half of its file
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                         : "+v"(acc)
+                         : "v"(__builtin_bit_cast(f32x4, a)), "a"(__builtin_bit_cast(f32x4, b)));
+        else if constexpr (ASM_)
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
                          : "+v"(acc)
                          : "v"(__builtin_bit_cast(f32x4, a)), "v"(__builtin_bit_cast(f32x4, b)));
@@ -242,7 +280,11 @@ struct OpBF16T {
     // interval's last MFMAs — a read hazard (caught by tools/check_mfma_hazards.py).
     __device__ static __forceinline__ void mma16_seed(const float4 &a, const float4 &b, f32x4 &acc, const f32x4 &c)
     {
-        if constexpr (ASM_)
+        if constexpr (ASM_ && QB_ == 4)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
+                         : "+v"(acc)
+                         : "v"(__builtin_bit_cast(f32x4, a)), "a"(__builtin_bit_cast(f32x4, b)), "v"(c));
+        else if constexpr (ASM_)
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
                          : "+v"(acc)
                          : "v"(__builtin_bit_cast(f32x4, a)), "v"(__builtin_bit_cast(f32x4, b)), "v"(c));
@@ -255,9 +297,15 @@ struct OpBF16T {
     // __builtin_amdgcn_sched_barrier keeps them there; the kernel's tail reads right behind the
     // last MFMAs and needs the explicit wait, with the accumulators as in/out operands so that
     // the reads are ordered behind it.
-    __device__ static __forceinline__ void mma16_tail_fence(AccSet16 &c)
+    template <class A>
+    __device__ static __forceinline__ void mma16_tail_fence(A &c)
     {
-        if constexpr (ASM_) asm volatile("s_nop 7" : "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13));
+        if constexpr (ASM_ && QB_ == 4) {
+            // (volatile statements keep their order: the pins, and every read of the tiles behind them, follow the wait)
+            asm volatile("s_nop 7");
+            asm volatile("" : "+v"(c.template at<1, 0>()), "+v"(c.template at<1, 1>()), "+v"(c.template at<1, 2>()), "+v"(c.template at<1, 3>()));
+            asm volatile("" : "+v"(c.template at<1, 4>()), "+v"(c.template at<1, 5>()), "+v"(c.template at<1, 6>()), "+v"(c.template at<1, 7>()));
+        } else if constexpr (ASM_) asm volatile("s_nop 7" : "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13));
         // (builtin MFMAs: hipcc's hazard recognizer places the wait states)
     }
 };
@@ -268,6 +316,8 @@ using OpBF16K128 = OpBF16T<8>;    // KT = 128: k <= 128 without padding to 256 (
 // MFMAs (the 32x32x16 form of OpBF16K512: one — LDS-bandwidth bound at 55 % of peak).  Compiler builtins
 // instead of inline asm: an asm "v" operand must sit in the 256 architectural VGPRs.
 using OpBF16K512T = OpBF16T<32, 4, false>;
+// KT = 256 with 128 queries per wave on four waves (experiment, -DNNS_BF16_WIDE): half the LDS fragment reads per MFMA
+using OpBF16Wide = OpBF16T<16, 4, true, 4>;
 
 
 // OpBF16T32: v_mfma_f32_32x32x16_bf16 (the first version; kept for A/B builds with
@@ -298,7 +348,10 @@ using OpBF16K512 = OpBF16T32T<32, 1>;
 // step 0 of the even slot, retired at step 31 of the odd one.  One MFMA per 1 KiB LDS fragment, like the
 // 512-deep tile: LDS-bandwidth bound (~50 % of the bf16 MFMA peak), still ~50x the exact VALU scan.
 using OpBF16K1024 = OpBF16T32T<64, 1, 4>;
-#if NNS_BF16_TILE16
+#if defined(NNS_BF16_WIDE)
+using OpBF16Active = OpBF16Wide;
+using OpBF16K512Active = OpBF16K512T;
+#elif NNS_BF16_TILE16
 using OpBF16Active = OpBF16;
 using OpBF16K512Active = OpBF16K512T;
 #else
@@ -362,7 +415,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
     constexpr int QB = OP::kQB;
-    static_assert(QB <= 2, "the accumulator sets hold two query blocks");
+    static_assert(QB <= 2 || OP::kTile16, "the 32x32 accumulator sets hold two query blocks");
     const int qblk0 = (blockIdx.x * F_NW + wave) * QB;
     // Lane STATES: the running minimum / threshold / candidate list a lane keeps per query it
     // carries.  32x32 tiles: one query per query block (state = block, 16 scores per ref block);
@@ -391,13 +444,16 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     for (int st = 0; st < NS; ++st) {
 #pragma unroll
         for (int b = 0; b < NBQ; ++b)
-            asm volatile("" : "+v"(bq[st][b].x), "+v"(bq[st][b].y), "+v"(bq[st][b].z), "+v"(bq[st][b].w));
+            if constexpr (T16 && QB > 2)   // (AGPR-resident operands: see OpBF16T::mma16)
+                asm volatile("" : "+a"(bq[st][b].x), "+a"(bq[st][b].y), "+a"(bq[st][b].z), "+a"(bq[st][b].w));
+            else
+                asm volatile("" : "+v"(bq[st][b].x), "+v"(bq[st][b].y), "+v"(bq[st][b].z), "+v"(bq[st][b].w));
         asm volatile("" : "+v"(tc[st].c0), "+v"(tc[st].c1), "+v"(tc[st].x2));
     }
     // The tau constants of the lane's states live in LDS behind the ring (2 KiB per wave, read only on
     // the slow path) instead of 3 registers per state; c1 depends on the tile depth alone and is
     // wave-uniform
-    float *tcl = reinterpret_cast<float *>(smem + F_LDS_BYTES) + wave * 512 + lane;
+    float *tcl = reinterpret_cast<float *>(smem + F_LDS_BYTES) + wave * (NS > 4 ? 1024 : 512) + lane;
     if constexpr (!OP::kTauInRegs) {
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
@@ -672,16 +728,25 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     };
 
     // ---- 16x16 tiles: one step, with the other ref tile's record collection folded in --------
-    float tmh[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // minima of the retiring ref tile, one per state
-    unsigned long long hm[4] = {0ull, 0ull, 0ull, 0ull};
+    constexpr int NT16 = T16 ? NS : 4;
+    float tmh[NT16];   // minima of the retiring ref tile, one per state
+    unsigned long long hm[NT16];
+#pragma unroll
+    for (int i = 0; i < NT16; ++i) {
+        tmh[i] = 0.0f;
+        hm[i] = 0ull;
+    }
     // threshold test of the retiring ref tile ot of block oblk: ONE wave-uniform branch for the
     // common case (no lane has a record in any of its four states), then per state inside
     auto t16_test = [&](typename OP::Acc &acc, int oblk, auto ot_c) __attribute__((always_inline)) {
         if constexpr (T16) {
             constexpr int ot = decltype(ot_c)::value;
-            if (__builtin_expect((hm[0] | hm[1] | hm[2] | hm[3]) != 0ull, 0)) {   // cold: laid out off the MFMA stream
+            unsigned long long any = 0ull;
+#pragma unroll
+            for (int i = 0; i < NT16; ++i) any |= hm[i];
+            if (__builtin_expect(any != 0ull, 0)) {   // cold: laid out off the MFMA stream
                 const int jbase = oblk * 32 + 16 * ot + 4 * (lane >> 4);
-                static_for<4>([&](auto st_c) __attribute__((always_inline)) {
+                static_for<NT16>([&](auto st_c) __attribute__((always_inline)) {
                     constexpr int st = decltype(st_c)::value;
                     if (hm[st] != 0ull) {
                         const f32x4 &o = acc.template at<ot, st>();
@@ -698,7 +763,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // SGPR pairs, computed a step before the branch that reads them)
     auto t16_masks = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int st = 0; st < 4; ++st) hm[st] = __builtin_amdgcn_ballot_w64(tmh[st] <= thr[st]);
+        for (int st = 0; st < NT16; ++st) hm[st] = __builtin_amdgcn_ballot_w64(tmh[st] <= thr[st]);
     };
     // step b = 8 rt + ks of the block blk_global: the 4 MFMAs of ref tile rt's k-step ks; at
     // ks = 1 the other tile's four accumulators (finished at its k-step 7, >= 5 MFMAs ago) are
@@ -710,7 +775,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             constexpr int NKS = SPB / 2;              // k-steps of 32 dims per 16-ref tile
             static_assert(NKS >= 3, "the other tile is retired at k-steps 1 and 2");
             constexpr int rt = b / NKS, ks = b % NKS, ot = 1 - rt;
-            static_for<4>([&](auto qc) __attribute__((always_inline)) {
+            static_for<NT16>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int qt = decltype(qc)::value;
                 if constexpr (ks == 0) OP::mma16_seed(frag, bq[qt][0], acc.template at<rt, qt>(), rt == 0 ? nseed0 : nseed1);
                 else OP::mma16(frag, bq[qt][ks], acc.template at<rt, qt>());
@@ -749,7 +814,10 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     typename OP::Acc acc;
     if constexpr (T16) {
         const f32x4 inf4 = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
-        acc.t00 = acc.t01 = acc.t02 = acc.t03 = acc.t10 = acc.t11 = acc.t12 = acc.t13 = inf4;
+        static_for<NT16>([&](auto qc) __attribute__((always_inline)) {
+            acc.template at<0, decltype(qc)::value>() = inf4;
+            acc.template at<1, decltype(qc)::value>() = inf4;
+        });
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc.v0[r] = acc.v1[r] = __builtin_inff();
@@ -908,7 +976,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     if constexpr (T16) {   // ref tile 1 of the last block is still to be retired
         OP::mma16_tail_fence(acc);
         if constexpr ((kAblate & 2) == 0) {
-            static_for<4>([&](auto qc) __attribute__((always_inline)) {
+            static_for<NT16>([&](auto qc) __attribute__((always_inline)) {
                 const f32x4 &o = acc.template at<1, decltype(qc)::value>();
                 tmh[decltype(qc)::value] = fminf(fminf(fminf(o[0], o[1]), o[2]), o[3]);
             });
@@ -1098,7 +1166,7 @@ static int launch_filter_t(const FilterGeom &g, const FilterArgs &args, hipStrea
 {
     auto kern = filter_kernel<OP>;
     // + 2 KiB per wave for the lanes' tau constants
-    constexpr int lds_bytes = F_LDS_BYTES + OP::kNW * 2048;
+    constexpr int lds_bytes = F_LDS_BYTES + OP::kNW * ((OP::kTile16 && OP::kQB > 2) ? 4096 : 2048);
     // > 64 KiB of dynamic LDS needs the opt-in, once per device
     static std::atomic<bool> attr_set[64];   // (two threads racing here both set it: harmless)
     int dev = 0;
