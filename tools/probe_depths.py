@@ -12,6 +12,8 @@ CASES = [(16, "f32"), (32, "f32"), (64, "f32"), (128, "f32"), (256, "f32"), (512
          (128, "bf16"), (256, "bf16"), (512, "bf16"), (1024, "bf16")]
 if "--deep" in sys.argv:
     CASES = [(1024, "f32"), (1024, "bf16"), (600, "bf16")]
+if "--k16" in sys.argv:     # the shallow fp32 tiles only
+    CASES = [(16, "f32"), (32, "f32")]
 if "--nw4" in sys.argv:     # the one-wave-per-SIMD tiles only
     CASES = [(512, "bf16"), (1024, "bf16")]
 if "--k512" in sys.argv:
