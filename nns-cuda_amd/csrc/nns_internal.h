@@ -34,7 +34,7 @@ hipError_t pool_alloc(void **out, size_t bytes);
 template <class T> static inline hipError_t pool_alloc(T **out, size_t bytes) { return pool_alloc((void **)out, bytes); }
 void pool_free(void *ptr);     // caller has synchronised the work that used ptr
 size_t pool_trim();            // give every parked block back to the runtime
-void stager_release();         // free the whole-call paths' pinned staging ring (nns_api.hip)
+void stager_release();         // free the small whole calls' pinned scratch (nns_api.hip)
 
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t divup64(int64_t a, int64_t b) { return (a + b - 1) / b; }
