@@ -821,6 +821,71 @@ static bool chunked_pays(int k, int64_t m, int64_t n, int bf16, unsigned flags, 
     return est_s >= 0.5e-3;
 }
 
+// the core: refs of the contiguous range [base, base + n) go up chunk by chunk into r_d and are searched (queries
+// resident in q_d) as they land; returns when the range's packed keys are complete in `keys` (device memory)
+static int search_range_overlapped_impl(int device, int k, int m, int n, const void *q_d, const void *r_host, char *r_d,
+                                        int bf16, int64_t base, unsigned flags, nns_key *keys, nns_key *keys_tmp)
+{
+    const size_t esz = bf16 ? sizeof(uint16_t) : sizeof(float);
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        return NNS_ERR_UNSUPPORTED;
+    }
+    std::vector<nns_index *> shards;
+    int rc = NNS_OK;
+    // chunks of 1/8, 1/4, 5/16, 5/16 of the refs (multiples of 512: whole ring slots at every tile depth)
+    int bounds[5] = {0, 0, 0, 0, n};
+    {
+        const int64_t unit = 512;
+        bounds[1] = (int)(((int64_t)n * 2 / 16 + unit - 1) / unit * unit);
+        bounds[2] = (int)(((int64_t)n * 6 / 16 + unit - 1) / unit * unit);
+        bounds[3] = (int)(((int64_t)n * 11 / 16 + unit - 1) / unit * unit);
+        for (int c = 1; c < 4; ++c)
+            if (bounds[c] > n) bounds[c] = n;
+    }
+    bool first = true;
+    for (int c = 0; c < 4 && rc == NNS_OK; ++c) {
+        const int beg = bounds[c], cnt = bounds[c + 1] - bounds[c];
+        if (cnt <= 0) continue;
+        // synchronous: the chunk is on the device when this returns; the previous chunk's search keeps running
+        if (hipMemcpy(r_d + (size_t)beg * k * esz, (const char *)r_host + (size_t)beg * k * esz, (size_t)cnt * k * esz,
+                      hipMemcpyHostToDevice) != hipSuccess) {
+            rc = NNS_ERR_HIP;
+            break;
+        }
+        nns_index *ix = nullptr;
+        rc = index_create_impl(&ix, device, k, cnt, r_d + (size_t)beg * k * esz, bf16, base + beg, flags | kCreateNoSync, st);
+        if (rc != NNS_OK) break;
+        shards.push_back(ix);
+        rc = index_search_impl(ix, m, q_d, bf16, first ? keys : keys_tmp, st);
+        if (rc == NNS_OK && !first) rc = nns_keys_min(keys, keys_tmp, m, st);
+        first = false;
+    }
+    if (rc == NNS_OK && hipStreamSynchronize(st) != hipSuccess) rc = NNS_ERR_HIP;
+    if (rc == NNS_ERR_HIP) set_error("nns_search (chunked upload): %s", hipGetErrorString(hipGetLastError()));
+    (void)hipDeviceSynchronize();   // the shards' workspaces go back to the pool: nothing may still use them
+    for (nns_index *ix : shards) nns_index_destroy(ix);
+    (void)hipStreamDestroy(st);
+    return rc;
+}
+
+extern "C++" {
+namespace nns {
+// for nns_multi.hip: one GPU's shard of nns_search_*_multi takes the same overlapped upload
+bool upload_overlap_pays(int k, int64_t m, int64_t n, int bf16, unsigned flags, size_t rbytes)
+{
+    if ((flags & NNS_PATH_MASK) == NNS_PATH_AUTO && (m < kTinyM || (!bf16 && small_exact(k, m, n)))) flags |= NNS_PATH_EXACT;
+    return chunked_pays(k, m, n, bf16, flags, rbytes);
+}
+int search_range_overlapped(int device, int k, int m, int n, const void *q_d, const void *r_host, char *r_d, int bf16,
+                            int64_t base, unsigned flags, nns_key *keys, nns_key *keys_tmp)
+{
+    return search_range_overlapped_impl(device, k, m, n, q_d, r_host, r_d, bf16, base, flags, keys, keys_tmp);
+}
+}  // namespace nns
+}  // extern "C++"
+
 static int search_host_chunked(int k, int m, int n, const void *s_points, const void *r_points, int bf16,
                                int *idx_out, float *dist_out, unsigned flags, int device)
 {
@@ -830,14 +895,8 @@ static int search_host_chunked(int k, int m, int n, const void *s_points, const 
     float *dist_d = nullptr;
     nns_key *keys = nullptr, *keys_tmp = nullptr;
     int *idx_d = nullptr;
-    hipStream_t st = nullptr;
-    std::vector<nns_index *> shards;
     int rc = NNS_OK;
     do {
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
-            (void)hipGetLastError();
-            return NNS_ERR_UNSUPPORTED;
-        }
         if (pool_alloc(&q_d, qb) != hipSuccess || pool_alloc(&r_d, rb) != hipSuccess ||
             pool_alloc(&keys, (size_t)m * sizeof(nns_key)) != hipSuccess ||
             pool_alloc(&keys_tmp, (size_t)m * sizeof(nns_key)) != hipSuccess ||
@@ -848,50 +907,21 @@ static int search_host_chunked(int k, int m, int n, const void *s_points, const 
             break;
         }
         if (hipMemcpy(q_d, s_points, qb, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("nns_search (chunked upload): %s", hipGetErrorString(hipGetLastError()));
             rc = NNS_ERR_HIP;
             break;
         }
-        // chunks of 1/8, 1/4, 5/16, 5/16 of the refs (multiples of 512: whole ring slots at every tile depth)
-        int bounds[5] = {0, 0, 0, 0, n};
-        {
-            const int64_t unit = 512;
-            bounds[1] = (int)(((int64_t)n * 2 / 16 + unit - 1) / unit * unit);
-            bounds[2] = (int)(((int64_t)n * 6 / 16 + unit - 1) / unit * unit);
-            bounds[3] = (int)(((int64_t)n * 11 / 16 + unit - 1) / unit * unit);
-            for (int c = 1; c < 4; ++c)
-                if (bounds[c] > n) bounds[c] = n;
-        }
-        bool first = true;
-        for (int c = 0; c < 4 && rc == NNS_OK; ++c) {
-            const int beg = bounds[c], cnt = bounds[c + 1] - bounds[c];
-            if (cnt <= 0) continue;
-            // synchronous: the chunk is on the device when this returns; the previous chunk's search keeps running
-            if (hipMemcpy(r_d + (size_t)beg * k * esz, (const char *)r_points + (size_t)beg * k * esz, (size_t)cnt * k * esz,
-                          hipMemcpyHostToDevice) != hipSuccess) {
-                rc = NNS_ERR_HIP;
-                break;
-            }
-            nns_index *ix = nullptr;
-            rc = index_create_impl(&ix, device, k, cnt, r_d + (size_t)beg * k * esz, bf16, beg, flags | kCreateNoSync, st);
-            if (rc != NNS_OK) break;
-            shards.push_back(ix);
-            rc = index_search_impl(ix, m, q_d, bf16, first ? keys : keys_tmp, st);
-            if (rc == NNS_OK && !first) rc = nns_keys_min(keys, keys_tmp, m, st);
-            first = false;
-        }
+        rc = search_range_overlapped_impl(device, k, m, n, q_d, r_points, r_d, bf16, 0, flags, keys, keys_tmp);
+        if (rc != NNS_OK) break;      // (UNSUPPORTED: no stream — the caller takes the plain path)
+        rc = nns_keys_unpack(keys, m, idx_d, dist_d, nullptr);
         if (rc != NNS_OK) break;
-        rc = nns_keys_unpack(keys, m, idx_d, dist_d, st);
-        if (rc != NNS_OK) break;
-        if (hipStreamSynchronize(st) != hipSuccess ||
-            hipMemcpy(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+        if (hipMemcpy(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
             (dist_out && hipMemcpy(dist_out, dist_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
+            set_error("nns_search (chunked upload): D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
             rc = NNS_ERR_HIP;
         }
     } while (0);
-    if (rc == NNS_ERR_HIP) set_error("nns_search (chunked upload): %s", hipGetErrorString(hipGetLastError()));
     (void)hipDeviceSynchronize();   // the blocks go back to the pool: nothing may still use them
-    for (nns_index *ix : shards) nns_index_destroy(ix);
-    if (st) (void)hipStreamDestroy(st);
     pool_free(q_d);
     pool_free(r_d);
     pool_free(keys);

@@ -35,6 +35,10 @@ template <class T> static inline hipError_t pool_alloc(T **out, size_t bytes) { 
 void pool_free(void *ptr);     // caller has synchronised the work that used ptr
 size_t pool_trim();            // give every parked block back to the runtime
 void stager_release();         // free the small whole calls' pinned scratch (nns_api.hip)
+// the overlapped upload of a contiguous host ref range (nns_api.hip), shared with nns_search_*_multi's shards
+bool upload_overlap_pays(int k, int64_t m, int64_t n, int bf16, unsigned flags, size_t rbytes);
+int search_range_overlapped(int device, int k, int m, int n, const void *q_d, const void *r_host, char *r_d, int bf16,
+                            int64_t base, unsigned flags, nns_key *keys, nns_key *keys_tmp);
 
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t divup64(int64_t a, int64_t b) { return (a + b - 1) / b; }

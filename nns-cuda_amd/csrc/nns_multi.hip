@@ -135,6 +135,17 @@ static void run_shard(ShardJob *job, int k, int m, int n, const void *q, const v
         // a dense [k][cnt] device array, which the index transposes (NNS_REFS_SOA)
         up = up && hipMemcpy2D(job->r_d, (size_t)job->cnt * esz, (const char *)r + (size_t)job->beg * esz,
                                (size_t)n * esz, (size_t)job->cnt * esz, (size_t)k, hipMemcpyHostToDevice) == hipSuccess;
+    } else if (up && upload_overlap_pays(k, m, job->cnt, bf16, flags, rb)) {
+        // a shard worth it goes up in chunks that are searched while the next one is copied (nns_api.hip)
+        nns_key *tmp = nullptr;
+        if (pool_alloc(&tmp, (size_t)m * sizeof(nns_key)) != hipSuccess) return fail(NNS_ERR_NOMEM, "device allocation");
+        const int orc = search_range_overlapped(job->device, k, m, job->cnt, job->q_d, (const char *)r + (size_t)job->beg * k * esz,
+                                                job->r_d, bf16, job->beg, flags, job->keys, tmp);
+        (void)hipDeviceSynchronize();
+        pool_free(tmp);
+        if (orc == NNS_OK) return;
+        if (orc != NNS_ERR_UNSUPPORTED) return fail(orc, "search (overlapped upload)");
+        up = hipMemcpy(job->r_d, (const char *)r + (size_t)job->beg * k * esz, rb, hipMemcpyHostToDevice) == hipSuccess;
     } else {
         up = up && hipMemcpy(job->r_d, (const char *)r + (size_t)job->beg * k * esz, rb, hipMemcpyHostToDevice) == hipSuccess;
     }

@@ -1101,6 +1101,10 @@ def test_whole_call_pipelined_upload(pkg, orc):
         assert np.array_equal(_bits(dist), _bits(want_dist))
     assert np.array_equal(pkg.cudaCall(k, m, n, q, r), want_idx)
     assert np.array_equal(pkg.search(q, r, shards=3), want_idx)     # the plain (synchronous) path agrees
+    # the in-library multi-GPU entry takes the same overlapped upload per shard (two virtual shards of 64 MiB,
+    # two host threads on this one device; the cross-chunk tie also crosses the shard boundary)
+    mi, md = pkg.search_multi(q, r, num_devices=2, virtual=True, return_distances=True)
+    assert np.array_equal(mi, want_idx) and np.array_equal(_bits(md), _bits(want_dist))
     r2 = r.copy()
     r2[200000, 7] = np.nan
     with np.errstate(all="ignore"):
