@@ -97,6 +97,11 @@ enum {
 typedef uint64_t nns_key;
 #define NNS_KEY_NONE 0x7F80000000000000ull
 
+/* Most points one set (queries of a search, refs of an index or whole call) may hold: 2^31 - 2^20.  The reference's
+ * sizes and indices are `int` (core.cu:24-26); this library keeps int32 indices and leaves 2^20 of headroom below
+ * 2^31 for padded tile images and range ends.  Larger m or n: NNS_ERR_INVALID (shard the refs with index_base). */
+#define NNS_MAX_POINTS 0x7FF00000
+
 /* opaque handle: one device-resident, prepared shard of reference points */
 typedef struct nns_index nns_index;
 

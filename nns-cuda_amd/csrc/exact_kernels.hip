@@ -260,9 +260,10 @@ __global__ __launch_bounds__(64 * MAXNW) void exact_lane_query_kernel(
     __shared__ int s_last;
     const int nthreads = blockDim.x, nw = nthreads >> 6;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j0 = blockIdx.y * refs_per_split;
-    int j1 = j0 + refs_per_split;
-    if (j1 > n) j1 = n;
+    const int j0 = blockIdx.y * refs_per_split;   // (< n)
+    // (64-bit: j0 + refs_per_split passes 2^31 for the last range of a very large n)
+    const int64_t j1l = (int64_t)j0 + refs_per_split;
+    const int j1 = j1l > n ? n : (int)j1l;
 
     K1A_STAMP(0);
 #ifdef NNS_K1A_STAMPS
@@ -637,7 +638,8 @@ __global__ __launch_bounds__(256) void exact_lane_ref_kernel(
             best[u] = __builtin_inff();
             bidx[u] = 0;
         }
-        for (int j = blockIdx.x * 256 + tid; j < n; j += gridDim.x * 256) {
+        for (int64_t jl = (int64_t)blockIdx.x * 256 + tid; jl < n; jl += (int64_t)gridDim.x * 256) {   // (64-bit: the stride may carry past 2^31)
+            const int j = (int)jl;
             const T *rj = r + (size_t)j * k;
             float sum[QT];
 #pragma unroll
@@ -756,7 +758,8 @@ __global__ __launch_bounds__(256) void exact_lane_ref_tiled_kernel(
         }
         // this wave's rows: groups of 64, strided over all waves of the grid
         const int wave_global = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
-        for (int row0 = wave_global * 64; row0 < n; row0 += nwaves * 64) {
+        for (int64_t row0l = (int64_t)wave_global * 64; row0l < n; row0l += (int64_t)nwaves * 64) {   // (64-bit: see above)
+            const int row0 = (int)row0l;
             float sum[QT];
 #pragma unroll
             for (int u = 0; u < QT; ++u) sum[u] = 0.0f;

@@ -40,6 +40,8 @@ static size_t norm_bytes(const FilterGeom &g, int pts_pad) { return ((size_t)pts
 // below this many queries the AUTO path skips the MFMA filter (and, in the whole-call
 // entry points, its ref pre-pass too)
 static const int kTinyM = 64;
+// most points a set may hold (nns.h NNS_MAX_POINTS): a margin of 2^20 below 2^31 for padded images and range ends
+static const int kMaxPoints = NNS_MAX_POINTS;
 // internal create flag (never set by callers: masked off at the C ABI): build the index without the
 // synchronising read-back of K2's max-|value| word; K5's device-side check then covers NaN / INF / huge refs
 static const unsigned kCreateNoSync = 1u << 30;
@@ -203,6 +205,10 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
 {
     if (!out || !r_dev || k <= 0 || n <= 0) {
         set_error("nns_index_create: k, n must be > 0 and pointers non-null (k=%d n=%d)", k, n);
+        return NNS_ERR_INVALID;
+    }
+    if (n > kMaxPoints) {
+        set_error("nns_index_create: n = %d exceeds NNS_MAX_POINTS (%d): padded tile images and range ends must stay below 2^31", n, kMaxPoints);
         return NNS_ERR_INVALID;
     }
     if (index_base < 0 || index_base + (int64_t)n > 0x7FFFFFFFll) {
@@ -417,6 +423,10 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
     }
     if (!ix || !q_dev || !keys_dev || m <= 0) {
         set_error("nns_index_search: m must be > 0 and pointers non-null (m=%d)", m);
+        return NNS_ERR_INVALID;
+    }
+    if (m > kMaxPoints) {
+        set_error("nns_index_search: m = %d exceeds NNS_MAX_POINTS (%d)", m, kMaxPoints);
         return NNS_ERR_INVALID;
     }
     NNS_TRY(ensure_device_ok(ix->device));
@@ -939,6 +949,10 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
         set_error("nns_search_f32: k, m, n must be > 0 and pointers non-null (k=%d m=%d n=%d)", k, m, n);
         return NNS_ERR_INVALID;
     }
+    if (m > kMaxPoints || n > kMaxPoints) {
+        set_error("nns_search_f32: m = %d / n = %d exceeds NNS_MAX_POINTS (%d)", m, n, kMaxPoints);
+        return NNS_ERR_INVALID;
+    }
     if ((int64_t)k * m > 0x7FFFFFFFll * 4 || (int64_t)k * n > 0x7FFFFFFFll * 4) {
         set_error("nns_search_f32: point set too large for one call");
         return NNS_ERR_INVALID;
@@ -998,7 +1012,7 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
         bool first = true;
         for (int s = 0; s < num_shards && rc == NNS_OK; ++s) {
             const int beg = s * per;
-            const int cnt = (beg + per <= n) ? per : n - beg;
+            const int cnt = ((int64_t)beg + per <= n) ? per : n - beg;
             if (cnt <= 0) break;
             rc = index_create_impl(&ix, device, k, cnt, r_d + (size_t)beg * k * esz, bf16, beg, flags, st);
             if (rc != NNS_OK) break;

@@ -40,7 +40,9 @@ bool upload_overlap_pays(int k, int64_t m, int64_t n, int bf16, unsigned flags, 
 int search_range_overlapped(int device, int k, int m, int n, const void *q_d, const void *r_host, char *r_d, int bf16,
                             int64_t base, unsigned flags, nns_key *keys, nns_key *keys_tmp);
 
-static inline int divup(int a, int b) { return (a + b - 1) / b; }
+// (the sum in 64 bits: a + b - 1 passes 2^31 for a point count near NNS_MAX_POINTS and a large divisor — that is how
+//  a K1a plan for n = 2^31 - 2^20 once came out with a negative split count)
+static inline int divup(int a, int b) { return (int)(((int64_t)a + b - 1) / b); }
 static inline int64_t divup64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- packed keys --------------------------------------------------------------

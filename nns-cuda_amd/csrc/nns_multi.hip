@@ -190,7 +190,7 @@ static int search_multi_impl(int k, int m, int n, const void *s_points, const vo
     std::vector<ShardJob> jobs;
     for (int g = 0; g < G; ++g) {
         const int beg = g * per;
-        const int cnt = (beg + per <= n) ? per : n - beg;
+        const int cnt = ((int64_t)beg + per <= n) ? per : n - beg;
         if (cnt <= 0) break;
         ShardJob j;
         j.device = g % visible;

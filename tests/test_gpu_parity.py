@@ -1266,6 +1266,81 @@ def test_whole_call_chunked_upload_exact_path(pkg, orc):
     assert np.array_equal(pkg.search(q, r), orc.v0_search(q, r, threads=16)[0])
 
 
+@pytest.mark.timeout(900)
+def test_largest_ref_count_int32_boundary(pkg, orc):
+    """n = NNS_MAX_POINTS (2^31 - 2^20) one-dimensional refs, 8.6 GB resident: range ends, strides and padded sizes
+    of the exact kernels stay inside int32 (the last ref range's end is computed in 64 bits), the winner may sit in the
+    very last refs, and with only 2^24 distinct fp32 values in [0, 1) every query has thousands of exact ties — the
+    lowest index must win.  K1b (16 queries) and K1a (128 queries) against the oracle; one ref more is rejected."""
+    n, k = 0x7FF00000, 1
+    dev = torch.device("cuda", 0)
+    r_d = torch.empty((n, k), dtype=torch.float32, device=dev)
+    pkg.fill_uniform(r_d, 4242, 0)
+    r_d += 2.0                                    # refs in [2, 3): the planted points below are the only near ones
+    r_d[n - 3, 0] = 0.25
+    r_d[n - 2, 0] = 0.25                          # exact duplicate: n - 3 must win
+    r_d[7, 0] = 0.75
+    r_d[n - 1, 0] = 0.75                          # duplicate of an early ref: 7 must win
+    r_h = r_d.cpu().numpy()
+    q = np.full((128, k), 0.25, dtype=np.float32)
+    q[1::2] = 0.75
+    q[5] = 2.5                                    # in the cloud: thousands of exact ties, lowest index wins
+    q[6] = 2.999
+    want_idx, want_dist = orc.v0_search(q[:16], r_h, threads=16)
+    assert want_idx[0] == n - 3 and want_idx[1] == 7
+    ix = pkg.Index(r_d, path="exact")
+    for m in (16, 128):
+        idx, dist = ix.search(torch.from_numpy(q[:m]).to(dev), return_distances=True)
+        torch.cuda.synchronize()
+        idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+        assert np.array_equal(idx[:16], want_idx), (m, idx[:16], want_idx)
+        assert np.array_equal(_bits(dist[:16]), _bits(want_dist))
+        assert (idx[16:][0::2] == n - 3).all() and (idx[16:][1::2] == 7).all()
+    ix.close()
+    del r_d
+    torch.cuda.empty_cache()
+    pkg.trim()
+    with pytest.raises(pkg.NNSError):             # one more point than NNS_MAX_POINTS
+        big = torch.empty((n + 1, k), dtype=torch.float32, device=dev)
+        try:
+            pkg.Index(big, path="exact")
+        finally:
+            del big
+            torch.cuda.empty_cache()
+
+
+@pytest.mark.timeout(900)
+def test_largest_ref_count_through_the_filter(pkg):
+    """The same count (2^31 - 2^20 refs, 8-D: 68.7 GB of points + a 137 GB tile image resident — what 288 GB of HBM are
+    for) through the MFMA filter (16-deep tile): every query is a copy of a planted ref — first, last, on slot and split
+    edges, random — so its answer is that ref's index at distance 0 (no CPU oracle can hold this; duplicates of an 8-D
+    point among 2^31 have probability ~0).  Slot, image and list indices stay inside int32 / use 64-bit addressing."""
+    n, k = 0x7FF00000, 8
+    dev = torch.device("cuda", 0)
+    torch.cuda.empty_cache()
+    pkg.trim()
+    free, _total = torch.cuda.mem_get_info()
+    if free < 235 * 10**9:
+        pytest.skip(f"needs ~220 GB of device memory ({free / 1e9:.0f} GB free)")
+    r_d = torch.empty((n, k), dtype=torch.float32, device=dev)
+    pkg.fill_uniform(r_d, 77, 0)
+    rng = np.random.default_rng(77)
+    pos = np.unique(np.concatenate([[0, 1, 31, 32, 511, 512, n // 2 - 1, n // 2, n - 513, n - 512, n - 33, n - 32, n - 2, n - 1],
+                                    rng.integers(0, n, 50)])).astype(np.int64)
+    q_d = r_d[torch.from_numpy(pos).to(dev)].contiguous()
+    ix = pkg.Index(r_d)
+    idx, dist = ix.search(q_d, return_distances=True)
+    torch.cuda.synchronize()
+    st = ix.stats()
+    assert st["path"] == 2 and st["k_tile"] == 16, st
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), pos)
+    assert (dist.cpu().numpy() == 0.0).all()
+    ix.close()
+    del r_d, q_d
+    torch.cuda.empty_cache()
+    pkg.trim()
+
+
 def test_small_whole_call_scratch_path_and_its_size_boundary(pkg, orc):
     """Whole calls whose inputs + outputs fit the 2 MiB pinned scratch take one upload / one wait (search_host_small);
     just above it the plain path runs.  Both sides of the boundary, fp32 and bf16, distances, NaN refs (the small
