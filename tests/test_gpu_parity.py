@@ -1310,6 +1310,45 @@ def test_largest_ref_count_int32_boundary(pkg, orc):
 
 
 @pytest.mark.timeout(900)
+def test_largest_query_count_int32_boundary(pkg):
+    """m = NNS_MAX_POINTS queries in one search (1-D, 1000 distinct refs, K1a): query j is a copy of ref j mod 1000, so
+    its answer is j mod 1000 at distance 0 — checked on the device in slices (keys, indices and distances of 2^31 - 2^20
+    queries are 34 GB).  One query more is rejected."""
+    m, n, k = 0x7FF00000, 1000, 1
+    dev = torch.device("cuda", 0)
+    torch.cuda.empty_cache()
+    pkg.trim()
+    free, _total = torch.cuda.mem_get_info()
+    if free < 80 * 10**9:
+        pytest.skip(f"needs ~60 GB of device memory ({free / 1e9:.0f} GB free)")
+    r_d = (torch.arange(n, dtype=torch.float32, device=dev) * 0.37).reshape(n, k).contiguous()
+    q_d = torch.empty((m, k), dtype=torch.float32, device=dev)
+    step = 1 << 27
+    for a in range(0, m, step):                      # q[j] = r[j mod n], built in slices
+        b = min(m, a + step)
+        q_d[a:b] = r_d[torch.arange(a, b, device=dev) % n]
+    ix = pkg.Index(r_d, path="exact")
+    idx, dist = ix.search(q_d, return_distances=True)
+    torch.cuda.synchronize()
+    for a in range(0, m, step):
+        b = min(m, a + step)
+        want = (torch.arange(a, b, device=dev) % n).to(torch.int32)
+        assert bool(torch.equal(idx[a:b], want)), a
+        assert bool((dist[a:b] == 0).all()), a
+    del idx, dist
+    with pytest.raises(pkg.NNSError):
+        q2 = torch.empty((m + 1, k), dtype=torch.float32, device=dev)
+        try:
+            ix.search(q2)
+        finally:
+            del q2
+    ix.close()
+    del q_d, r_d
+    torch.cuda.empty_cache()
+    pkg.trim()
+
+
+@pytest.mark.timeout(900)
 def test_largest_ref_count_through_the_filter(pkg):
     """The same count (2^31 - 2^20 refs, 8-D: 68.7 GB of points + a 137 GB tile image resident — what 288 GB of HBM are
     for) through the MFMA filter (16-deep tile): every query is a copy of a planted ref — first, last, on slot and split
