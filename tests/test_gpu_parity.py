@@ -1266,6 +1266,22 @@ def test_whole_call_chunked_upload_exact_path(pkg, orc):
     assert np.array_equal(pkg.search(q, r), orc.v0_search(q, r, threads=16)[0])
 
 
+@pytest.mark.parametrize("shape", [(40, 700, 1025), (65, 500, 2048), (3, 300, 4099), (130, 257, 3000), (2, 100, 16384)])
+def test_dimensionality_beyond_the_filter_and_its_limit(pkg, orc, shape):
+    """k > 1024 has no MFMA tile: the exact lane-per-ref kernel runs it with the query tile in LDS (k <= 16384: 64 KiB),
+    fp32 and bf16, whole call and sharded; k = 16385 is refused with a status code, not a crash."""
+    m, n, k = shape
+    rng = np.random.default_rng(k)
+    q = (rng.random((m, k), dtype=np.float32) - 0.5) * 3
+    r = (rng.random((n, k), dtype=np.float32) - 0.5) * 3
+    r[n // 2] = q[0]                                  # an exact hit
+    _check(pkg, orc, q, r, paths=("auto", "exact"), shards=(1, 3))
+    _check_bf16(pkg, orc, q, r, paths=("auto",))
+    if k == 16384:
+        with pytest.raises(pkg.NNSError):
+            pkg.search(np.zeros((2, k + 1), np.float32), np.zeros((5, k + 1), np.float32))
+
+
 @pytest.mark.timeout(900)
 def test_largest_ref_count_int32_boundary(pkg, orc):
     """n = NNS_MAX_POINTS (2^31 - 2^20) one-dimensional refs, 8.6 GB resident: range ends, strides and padded sizes
