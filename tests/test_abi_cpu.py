@@ -42,6 +42,10 @@ def test_argument_validation_returns_status_not_exit(pkg):
     assert pkg.lib.nns_search_f32(3, 4, 4, q.ctypes.data, q.ctypes.data, None) == 1
     assert pkg.lib.nns_index_create(None, 0, 3, 4, q.ctypes.data, 0, 0, None) == 1
     assert b"nns_" in pkg.lib.nns_last_error()
+    # NNS_MAX_POINTS = 2^31 - 2^20 points per set (validated before anything is read or allocated)
+    idx = np.zeros(4, np.int32)
+    assert pkg.lib.nns_search_f32_ex(1, 4, 0x7FF00001, q.ctypes.data, q.ctypes.data, idx.ctypes.data, None, 1, 0, 0) == 1
+    assert b"NNS_MAX_POINTS" in pkg.lib.nns_last_error()
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device error path")
