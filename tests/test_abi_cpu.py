@@ -69,7 +69,7 @@ def test_shipped_library_has_no_diagnostic_switches(pkg):
     # the only environment variable the library reads: the pool cap
     # (other NNS_* strings are names of include/nns.h flags quoted in error messages)
     names = {n for n in re.findall(rb"NNS_[A-Z_]{3,}", blob)
-             if not re.match(rb"NNS_(PATH_|FILTER_BF|REFS_SOA|COMM_ID_BYTES|MULTI_VIRTUAL|ERR_|KEY_NONE)", n)}
+             if not re.match(rb"NNS_(PATH_|FILTER_BF|REFS_SOA|COMM_ID_BYTES|MULTI_VIRTUAL|ERR_|KEY_NONE|MAX_POINTS)", n)}
     assert names == {b"NNS_POOL_BYTES"}, names
 
 
