@@ -1282,6 +1282,32 @@ def test_dimensionality_beyond_the_filter_and_its_limit(pkg, orc, shape):
             pkg.search(np.zeros((2, k + 1), np.float32), np.zeros((5, k + 1), np.float32))
 
 
+def test_index_base_up_to_the_int32_limit(pkg, orc):
+    """A shard whose global indices end at 2^31 - 1 (index_base + n = 2^31 - 1 is the last legal placement; one more is
+    refused): exact and MFMA paths return base + local index as positive int32, keys order by (distance, global index)."""
+    rng = np.random.default_rng(31)
+    dev = torch.device("cuda", 0)
+    for k, n, m in ((3, 5000, 300), (128, 3000, 200), (16, 70000, 1100)):
+        q = rng.random((m, k), dtype=np.float32)
+        r = rng.random((n, k), dtype=np.float32)
+        r[n - 1] = r[4]                                        # a tie inside the shard: the lower global index wins
+        q[0] = r[4]
+        base = 0x7FFFFFFF - n
+        want_idx, want_dist = orc.v0_search(q, r, threads=8)
+        r_d, q_d = torch.from_numpy(r).to(dev), torch.from_numpy(q).to(dev)
+        for path in ("auto", "exact"):
+            ix = pkg.Index(r_d, index_base=base, path=path)
+            idx, dist = ix.search(q_d, return_distances=True)
+            torch.cuda.synchronize()
+            got = idx.cpu().numpy()
+            assert got.dtype == np.int32 and (got > 0).all()
+            assert np.array_equal(got.astype(np.int64) - base, want_idx), (k, path)
+            assert np.array_equal(_bits(dist.cpu().numpy()), _bits(want_dist))
+            ix.close()
+        with pytest.raises(pkg.NNSError):
+            pkg.Index(r_d, index_base=base + 1)
+
+
 @pytest.mark.timeout(900)
 def test_largest_ref_count_int32_boundary(pkg, orc):
     """n = NNS_MAX_POINTS (2^31 - 2^20) one-dimensional refs, 8.6 GB resident: range ends, strides and padded sizes
