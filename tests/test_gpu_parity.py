@@ -1342,6 +1342,14 @@ def test_largest_ref_count_int32_boundary(pkg, orc):
     del r_d
     torch.cuda.empty_cache()
     pkg.trim()
+    # the whole-call entry on the same host array (8.6 GB pageable upload): plain path (16 queries) and the chunked,
+    # overlapped upload (128 queries: four chunks of up to 6.7e8 refs, global indices carried by index_base)
+    for m in (16, 128):
+        idx, dist = pkg.search(q[:m], r_h, return_distances=True)
+        assert np.array_equal(idx[:16], want_idx), (m, idx[:16])
+        assert np.array_equal(_bits(dist[:16]), _bits(want_dist))
+        assert (idx[16:][0::2] == n - 3).all() and (idx[16:][1::2] == 7).all()
+    del r_h
     with pytest.raises(pkg.NNSError):             # one more point than NNS_MAX_POINTS
         big = torch.empty((n + 1, k), dtype=torch.float32, device=dev)
         try:
