@@ -35,8 +35,12 @@
  * Layouts: queries s_points[m][k], refs r_points[n][k], row-major fp32
  * (core.cu:41); results int32[m], 0-based global ref index.
  *
- * Threading: one caller thread per nns_index; the whole-call entry points are
- * re-entrant (no globals).  All device work of the split API is enqueued on
+ * Threading: one caller thread per nns_index, and searches of ONE index must not
+ * overlap in time (its workspaces, incl. the exact kernel's merge accumulator, belong
+ * to the index: use one index per stream).  The whole-call entry points are
+ * re-entrant: the process-wide caches behind them (workspace pool, the small-call
+ * scratch, RCCL communicators) are internally synchronised, and a call that finds the
+ * scratch busy takes the plain path.  All device work of the split API is enqueued on
  * the caller's HIP stream and is asynchronous unless stated.
  */
 #ifndef NNS_MI355X_H
