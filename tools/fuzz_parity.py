@@ -65,6 +65,10 @@ def main():
         n = int(rng.choice([1, 5, 31, 64, 65, 257, 1000, 4097, 20001, 70000, 150000]))
         while float(m) * n * k > a.max_pairs * 64:
             n = max(1, n // 2)
+        # now and then a whole call big enough for the chunked, overlapped upload (>= 8 MiB of refs, search >= 0.5 ms)
+        if rng.integers(0, 40) == 0:
+            k, m, n = [(3, 4096, 700000), (16, 4096, 600000), (128, 4096, 70000)][int(rng.integers(0, 3))]
+            n += int(rng.integers(0, 1000))
         fam = str(rng.choice(families))
         bf16 = bool(rng.integers(0, 3) == 0) and fam not in ("huge",)
         path = str(rng.choice(["auto", "auto", "mfma", "exact"]))
