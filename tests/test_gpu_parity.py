@@ -1282,6 +1282,42 @@ def test_dimensionality_beyond_the_filter_and_its_limit(pkg, orc, shape):
             pkg.search(np.zeros((2, k + 1), np.float32), np.zeros((5, k + 1), np.float32))
 
 
+def test_split_api_on_side_streams(pkg, orc):
+    """Everything the split API enqueues goes to the CALLER's stream (include/nns.h): two indexes searched from two
+    non-blocking side streams at once, results consumed on those streams — exact kernel (merge accumulator armed and
+    re-armed on the stream), MFMA filter (prep, filter, finalize, re-rank), refresh + fused index unpack.  A launch
+    that strayed onto the default stream would race with the side streams' work and show up as wrong answers."""
+    rng = np.random.default_rng(2024)
+    dev = torch.device("cuda", 0)
+    cases = []
+    for k, m, n in ((3, 3000, 120000), (128, 1500, 60000), (16, 2000, 90000), (256, 700, 30000)):
+        q = rng.random((m, k), dtype=np.float32)
+        r = rng.random((n, k), dtype=np.float32)
+        cases.append((torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev), orc.v0_search(q, r, threads=16)))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in cases]
+    idxs = [pkg.Index(r_d) for (_q, r_d, _w) in cases]            # built on the default stream, synchronous
+    torch.cuda.synchronize()
+    outs = [None] * len(cases)
+    for rep in range(3):
+        for i, (q_d, r_d, _want) in enumerate(cases):             # enqueue everything first, then check
+            with torch.cuda.stream(streams[i]):
+                idxs[i].refresh()
+                keys = torch.empty(q_d.shape[0], dtype=torch.int64, device=dev)
+                idx = torch.empty(q_d.shape[0], dtype=torch.int32, device=dev)
+                dist = torch.empty(q_d.shape[0], dtype=torch.float32, device=dev)
+                idxs[i].search_indices(q_d, keys, idx, dist)
+                outs[i] = (idx, dist, idxs[i].search(q_d))        # the unfused form on the same stream
+        for i, (_q, _r, (want_idx, want_dist)) in enumerate(cases):
+            streams[i].synchronize()
+            idx, dist, idx2 = outs[i]
+            assert np.array_equal(idx.cpu().numpy(), want_idx), (rep, i)
+            assert np.array_equal(_bits(dist.cpu().numpy()), _bits(want_dist)), (rep, i)
+            assert np.array_equal(idx2.cpu().numpy(), want_idx), (rep, i)
+    for ix in idxs:
+        ix.close()
+
+
 def test_index_base_up_to_the_int32_limit(pkg, orc):
     """A shard whose global indices end at 2^31 - 1 (index_base + n = 2^31 - 1 is the last legal placement; one more is
     refused): exact and MFMA paths return base + local index as positive int32, keys order by (distance, global index)."""
