@@ -80,27 +80,107 @@ def _free_port():
     return p
 
 
-def self_launch(n):
+def _die_with_parent():
+    """preexec of the launcher child (nothing has touched the GPU there): SIGTERM when this process dies, however
+    it dies — a SIGKILL (the -k stage of `timeout -k`) cannot be forwarded, the kernel delivers this instead."""
+    try:
+        import ctypes
+        PR_SET_PDEATHSIG = 1
+        ctypes.CDLL(None, use_errno=True).prctl(PR_SET_PDEATHSIG, 15, 0, 0, 0)
+    except Exception:
+        pass
+
+
+def self_launch(n, grace_s=20.0):
     """Started without a launcher and asked for N > 1 GPUs: become the launcher.  Nothing in this
     process has touched the GPU yet (importing torch does not), so the ranks are clean children."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "1")        # what torchrun would set, without its warning
-    # stdout / stderr inherited: rank 0's JSON line is ours.  The launcher and its ranks get their own process
-    # group, so that a SIGTERM / SIGINT to this process (a driver's timeout) takes exactly them down with it
+    # stdout / stderr inherited: rank 0's JSON line is ours.  The launcher and its ranks get their own session, so
+    # that a signal to this process takes exactly them down with it: TERM / INT / HUP are forwarded to the group;
+    # if the group has not gone `grace_s` seconds after that (a rank stuck in a GPU call ignores SIGTERM) it is
+    # SIGKILLed and this process exits non-zero; and if THIS process is SIGKILLed the launcher gets SIGTERM from
+    # the kernel (PR_SET_PDEATHSIG) and takes its ranks down itself.
     import signal
-    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True, preexec_fn=_die_with_parent)
+    state = {"sig": None, "t": None}
 
     def _forward(signum, _frame):
+        if state["sig"] is None:
+            state["sig"], state["t"] = signum, time.monotonic()
         try:
             os.killpg(proc.pid, signum)
         except ProcessLookupError:
             pass
 
-    for sig in (signal.SIGTERM, signal.SIGINT):
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
         signal.signal(sig, _forward)
-    raise SystemExit(proc.wait())
+    while True:
+        try:
+            rc = proc.wait(timeout=0.5)
+            break
+        except subprocess.TimeoutExpired:
+            if state["t"] is not None and time.monotonic() - state["t"] > grace_s:
+                sys.stderr.write(f"bench.py: ranks still alive {grace_s:.0f} s after signal {state['sig']}: SIGKILL\n")
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.wait()
+                raise SystemExit(128 + int(state["sig"]))
+    if state["sig"] is not None and rc == 0:
+        rc = 128 + int(state["sig"])
+    raise SystemExit(rc)
+
+
+class Deadline:
+    """Bound one rendezvous step of a launched rank (process-group set-up, communicator creation, the first
+    collective): if it has not completed after `seconds`, say WHICH step on stderr and leave with a non-zero code
+    — the launcher then takes the other ranks down.  (A hung collective cannot be cancelled from inside; os._exit
+    from the watchdog thread works while the main thread sits in a C call.  Nothing is re-executed.)"""
+
+    def __init__(self, step, seconds, rank=0):
+        self.step, self.seconds, self.rank, self.timer = step, seconds, rank, None
+
+    def _fire(self):
+        sys.stderr.write(f"bench.py rank {self.rank}: rendezvous step '{self.step}' did not complete within "
+                         f"{self.seconds:.0f} s: giving up (exit 4)\n")
+        sys.stderr.flush()
+        os._exit(4)
+
+    def __enter__(self):
+        import threading
+        if self.seconds and self.seconds > 0:
+            self.timer = threading.Timer(self.seconds, self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
+
+
+def rank_report(dist, local, rehearse_or_cpu, dev=None):
+    """Outside the timed region: gather every rank's own numbers (all_gather_object) and condense them for rank 0's
+    line — per-rank step time (first step start -> own device idle, before the closing barrier), its min / max /
+    slowest rank, rank 0 against the slowest, and the device time of search and exchange per rank.  `local` is
+    this rank's {"step_ms", "search_ms", "exchange_ms"}."""
+    world = dist.get_world_size()
+    got = [None] * world
+    dist.all_gather_object(got, local)
+    steps = [float(g["step_ms"]) for g in got]
+    slow = int(np.argmax(steps))
+    return {"step_ms": [round(v, 4) for v in steps], "step_ms_min": round(min(steps), 4), "step_ms_max": round(max(steps), 4),
+            "slowest_rank": slow, "rank0_vs_slowest_ms": round(steps[slow] - steps[0], 4),
+            "search_ms": [round(float(g["search_ms"]), 4) for g in got],
+            "exchange_ms": [round(float(g["exchange_ms"]), 4) for g in got],
+            "note": "per rank: wall ms per step up to the rank's own device idle (before the closing barrier); "
+                    "search = K2 + filter + K5 + re-rank (HIP events inside the library); exchange = the min "
+                    "all-reduce between two events on the launch stream, which includes waiting for the slowest rank"}
 
 
 def cpu_baseline(orc, q_h, r_h, idx_gpu, target_s=12.0, full=False):
@@ -172,6 +252,24 @@ def baseline_sample(q, idx, cap=4096, seed=1000):
     return q[sel_t].float().cpu().numpy(), idx[sel_t].cpu().numpy()
 
 
+def parity_flags(node, path=""):
+    """Every cross-check the line carries (`matches_*`, `same_*`, `verified_*` booleans, at any depth) that is
+    False: the run then prints its line and exits non-zero."""
+    bad = []
+    if isinstance(node, dict):
+        for k_, v in node.items():
+            p_ = f"{path}.{k_}" if path else k_
+            if isinstance(v, bool) and (k_.startswith("matches_") or k_.startswith("same_") or k_.startswith("verified_")):
+                if not v:
+                    bad.append(p_)
+            else:
+                bad += parity_flags(v, p_)
+    elif isinstance(node, (list, tuple)):
+        for i, v in enumerate(node):
+            bad += parity_flags(v, f"{path}[{i}]")
+    return bad
+
+
 def load_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the committed PMC run (profiles/traffic.json,
     produced by tools/pmc_traffic.py from separate rocprofv3 --pmc passes over this same command,
@@ -190,9 +288,9 @@ def load_traffic(kernel_key):
 class Ctx:
     """What one rank needs to run workloads."""
 
-    def __init__(self, pkg, dev, rank, world, dist=None, comm=None, rehearse=False):
+    def __init__(self, pkg, dev, rank, world, dist=None, comm=None, rehearse=False, rendezvous_s=0.0):
         self.pkg, self.dev, self.rank, self.world = pkg, dev, rank, world
-        self.dist, self.comm, self.rehearse = dist, comm, rehearse
+        self.dist, self.comm, self.rehearse, self.rendezvous_s = dist, comm, rehearse, rendezvous_s
 
     def barrier(self):
         if self.dist is not None:
@@ -221,17 +319,31 @@ def run_workload(ctx, name, steps, warmup, seed=1000):
     ix = pkg.Index(r, index_base=beg, path="auto", profile=True, filter_bf16=mixed)
 
     idx_buf = torch.empty(m, dtype=torch.int32, device=dev)
+    # N > 1: HIP events around the exchange of every timed step (on the launch stream = torch's current stream)
+    ex_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] \
+        if dist is not None else []
+    ex_i = [-1]                               # index of the timed step being run (-1: warm-up)
 
     def step():
         ix.refresh()                          # K2 on refs
         if dist is None:                      # one shard: keys + unpacked indices from the search itself
             return ix.search_indices(q, keys, idx_buf)
         ix.search_keys(q, keys)               # K2 queries, K3 filter, K5, re-rank
+        if ex_i[0] >= 0:
+            ex_ev[ex_i[0]][0].record()
         pkg.allreduce_min_keys(keys, comm=ctx.comm)   # MINLOC-style exchange: one min all-reduce
+        if ex_i[0] >= 0:
+            ex_ev[ex_i[0]][1].record()
         return pkg.keys_unpack(keys)
 
-    for _ in range(warmup):
-        step()
+    # (N > 1: the FIRST collective of the run happens here — or below if there is no warm-up — under a deadline)
+    with Deadline("first min all-reduce of the packed keys", ctx.rendezvous_s if dist is not None else 0, rank):
+        for _ in range(warmup):
+            step()
+        if dist is not None:
+            if warmup == 0:
+                pkg.allreduce_min_keys(keys.clone().fill_(0), comm=ctx.comm)
+            torch.cuda.synchronize()
     stage = {"filter_ms": 0.0, "exact_ms": 0.0, "prep_refs_ms": 0.0, "prep_queries_ms": 0.0,
              "finalize_ms": 0.0, "rerank_ms": 0.0}
     ix.stats()                                # drop the warm-up steps' event sets
@@ -240,6 +352,7 @@ def run_workload(ctx, name, steps, warmup, seed=1000):
     done = 0
     idx = None
     for i in range(steps):
+        ex_i[0] = i
         idx = step()
         # HIP events of every step's kernels are recorded on the launch stream inside the
         # library; read (= one device sync) every 32 steps at most: its ring of event sets
@@ -248,8 +361,13 @@ def run_workload(ctx, name, steps, warmup, seed=1000):
             for f in stage:
                 stage[f] += st[f] * 32
             done += 32
+    local_elapsed = None
+    if dist is not None:
+        torch.cuda.synchronize()              # this rank's own device is idle: its own time, before the barrier
+        local_elapsed = time.perf_counter() - t0
     ctx.barrier()
     elapsed = time.perf_counter() - t0
+    ex_i[0] = -1
     st = ix.stats()                           # averages over the steps not read yet
     for f in stage:
         stage[f] += st[f] * (steps - done)
@@ -285,6 +403,14 @@ def run_workload(ctx, name, steps, warmup, seed=1000):
                 "hbm_GBs_algorithmic": ((m + n_local) * k * 4 + 4 * m) / (kern_ms * 1e-3) / 1e9}
     if tsrc:
         roof["traffic_source"] = tsrc
+    ranks = None
+    if dist is not None:
+        ex_ms = float(np.mean([a.elapsed_time(b) for a, b in ex_ev])) if ex_ev else 0.0
+        ranks = rank_report(dist, {"step_ms": local_elapsed / steps * 1e3,
+                                   "search_ms": stage["prep_refs_ms"] + (stage["prep_queries_ms"] + stage["filter_ms"]
+                                                                        + stage["finalize_ms"] + stage["rerank_ms"]
+                                                                        if mfma_path else stage["exact_ms"]),
+                                   "exchange_ms": ex_ms}, ctx.rehearse)
     out = {
         "metric": "query-point-pairs/s", "value": value, "unit": "pairs/s",
         "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -300,6 +426,8 @@ def run_workload(ctx, name, steps, warmup, seed=1000):
                    "ambiguous_queries": amb, "stage_ms": {f: round(v, 4) for f, v in stage.items()}},
         "roofline": roof,
     }
+    if ranks is not None:
+        out["ranks"] = ranks
     return out, idx, q, r, ix, keys
 
 
@@ -312,7 +440,12 @@ def selftest_launch(args):
     rank = int(os.environ.get("RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from datetime import timedelta
+    with Deadline("init_process_group(gloo)", args.rendezvous_timeout, rank):
+        if args.selftest_hang == "init" and rank == world - 1:
+            time.sleep(3600)                  # (tests: a rank that never reaches the rendezvous)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world,
+                                timeout=timedelta(seconds=max(5.0, args.rendezvous_timeout)))
     pkg = graft.load_package()
     m, n_total = 1000, 1000 * world
     beg, cnt = pkg.shard_range(n_total, world, rank)
@@ -320,7 +453,14 @@ def selftest_launch(args):
     i = torch.arange(m, dtype=torch.int64)
     d = ((i * 7 + rank * 3) % 11).to(torch.float32)
     keys = (d.view(torch.int32).to(torch.int64) << 32) | (beg + (i % cnt))
-    pkg.allreduce_min_keys(keys)
+    t_begin = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))             # the "search": rank r takes 10 (r + 1) ms, so the last rank is the slowest
+    t_search = time.perf_counter()
+    with Deadline("first min all-reduce of the packed keys", args.rendezvous_timeout, rank):
+        if args.selftest_hang == "exchange" and rank == world - 1:
+            time.sleep(3600)                  # (tests: a rank that never joins the collective)
+        pkg.allreduce_min_keys(keys)
+    t_end = time.perf_counter()
     # every rank can compute the expected merge
     want = None
     for rr in range(world):
@@ -331,8 +471,11 @@ def selftest_launch(args):
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if args.selftest_sleep > 0:
         time.sleep(args.selftest_sleep)       # (tests/test_bench_launch.py: signal forwarding)
+    # the per-rank attribution block of the N > 1 line, through the same function the measured path uses
+    ranks = rank_report(dist, {"step_ms": (t_search - t_begin) * 1e3, "search_ms": (t_search - t_begin) * 1e3,
+                               "exchange_ms": (t_end - t_search) * 1e3}, True)
     if rank == 0:
-        print(json.dumps({"selftest": "launch", "n_gpus": world, "ok": bool(ok.item()),
+        print(json.dumps({"selftest": "launch", "n_gpus": world, "ok": bool(ok.item()), "ranks": ranks,
                           "note": "gloo rendezvous + key exchange only: not a measurement"}), flush=True)
     dist.destroy_process_group()
 
@@ -353,6 +496,10 @@ def main():
                     help="N > 1: who issues the RCCL min all-reduce (auto: the library, torch.distributed if that fails)")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--selftest-sleep", type=float, default=0.0, help=argparse.SUPPRESS)
+    ap.add_argument("--selftest-hang", default="", choices=("", "init", "exchange"), help=argparse.SUPPRESS)
+    ap.add_argument("--rendezvous-timeout", type=float, default=240.0,
+                    help="N > 1: seconds a rank waits in process-group set-up, communicator creation or the first "
+                         "collective before it names the step on stderr and exits non-zero (0: unbounded)")
     args = ap.parse_args()
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -379,10 +526,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if args.rehearse_one_gpu:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        from datetime import timedelta
+        pg_to = timedelta(seconds=max(30.0, args.rendezvous_timeout)) if args.rendezvous_timeout > 0 else None
+        with Deadline("torch.distributed.init_process_group", args.rendezvous_timeout, rank):
+            if args.rehearse_one_gpu:
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world, **({"timeout": pg_to} if pg_to else {}))
+            else:
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev,
+                                        **({"timeout": pg_to} if pg_to else {}))
 
     pkg = graft.load_package()
 
@@ -399,25 +550,31 @@ def main():
                     uid[0] = pkg.comm_unique_id()
                 except pkg.NNSError as e:
                     exch["library_comm_error"] = str(e)
-            dist.broadcast_object_list(uid, src=0, device=dev)
+            with Deadline("broadcast of the RCCL unique id (first torch.distributed collective)", args.rendezvous_timeout, rank):
+                dist.broadcast_object_list(uid, src=0, device=dev)
+            t_comm = time.perf_counter()
             if uid[0] is not None:
                 try:
-                    comm = pkg.Comm(uid[0], world, rank, local_rank)
+                    with Deadline("nns_comm_create (ncclCommInitRank)", args.rendezvous_timeout, rank):
+                        comm = pkg.Comm(uid[0], world, rank, local_rank)
                 except pkg.NNSError as e:
                     comm = None
                     exch["library_comm_error"] = str(e)
+            t_comm = time.perf_counter() - t_comm
             ok = torch.tensor([1 if comm is not None else 0], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            with Deadline("agreement on the communicator (all_reduce)", args.rendezvous_timeout, rank):
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0 and comm is not None:
                 comm.close()
                 comm = None
             if comm is not None:
                 exch = {"impl": "nns_comm_allreduce_min: ncclAllReduce(ncclUint64, ncclMin) issued by libnns_mi355x "
-                                "(the call site nns_search_f32_multi uses)", "rccl_ranks": comm.size()}
+                                "(the call site nns_search_f32_multi uses)", "rccl_ranks": comm.size(),
+                        "comm_create_s": round(t_comm, 3)}
             elif args.exchange == "library":
                 raise SystemExit(f"--exchange library: {exch.get('library_comm_error', 'communicator not built')}")
 
-    ctx = Ctx(pkg, dev, rank, world, dist, comm, args.rehearse_one_gpu)
+    ctx = Ctx(pkg, dev, rank, world, dist, comm, args.rehearse_one_gpu, args.rendezvous_timeout)
     out, idx, q, r, ix, keys = run_workload(ctx, args.workload, args.steps, args.warmup)
     m, n_local, k, dtype = WORKLOADS[args.workload]
     n_total = n_local * world
@@ -440,6 +597,13 @@ def main():
 
     if rank == 0:
         if exch is not None:
+            if "ranks" in out:                 # the attribution block: where a step's time went, per rank
+                exch["exchange_ms"] = {"max_over_ranks": max(out["ranks"]["exchange_ms"]),
+                                       "min_over_ranks": min(out["ranks"]["exchange_ms"]),
+                                       "payload_bytes": 8 * m,
+                                       "note": "HIP events around the all-reduce on the launch stream, mean over the timed "
+                                               "steps; the minimum over ranks is the slowest rank's own cost of the collective, "
+                                               "the others' excess is time spent waiting for it"}
             out["exchange"] = exch
         if args.rehearse_one_gpu:
             out["rehearsal"] = "all ranks on one GPU, gloo exchange: NOT a measurement"
@@ -513,7 +677,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:                             # last thing on stdout (RCCL prints a banner at init)
+        bad = parity_flags(out)
+        out["parity_ok"] = not bad
+        if bad:
+            out["parity_failed"] = bad
         print(json.dumps(out), flush=True)
+        if bad:                               # a wrong answer must not look like a successful run
+            sys.stderr.write("bench.py: cross-checks FAILED: " + ", ".join(bad) + "\n")
+            raise SystemExit(3)
 
 
 if __name__ == "__main__":

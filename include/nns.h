@@ -42,6 +42,15 @@
  * scratch, RCCL communicators) are internally synchronised, and a call that finds the
  * scratch busy takes the plain path.  All device work of the split API is enqueued on
  * the caller's HIP stream and is asynchronous unless stated.
+ *
+ * Manners towards the host application:
+ *   - no entry point calls hipDeviceSynchronize(): destroy, workspace regrow and the whole-call exits hand
+ *     their device blocks back to the library's pool behind an EVENT on the stream that used them, read-outs
+ *     (nns_index_stats, nns_index_near_ties) wait for the index's own stream, and the whole-call entry points
+ *     run their kernels on a non-blocking stream of the library.  Kernels the application has running on
+ *     other streams are never waited for.  (The stream an index last worked on must still exist when the
+ *     index is destroyed; if it does not, destroy falls back to waiting for the device.)
+ *   - every entry point that selects a device restores the caller's current device before it returns.
  */
 #ifndef NNS_MI355X_H
 #define NNS_MI355X_H
@@ -84,10 +93,13 @@ enum {
                           * takes this filter by itself only for 256 < k <= 1024, where no fp32 tile exists (the
                           * alternative is the VALU scan); it is not what bench.py measures for the fp32
                           * configurations. */
-    NNS_REFS_SOA = 64    /* the reference points are given dimension-major, r[t * n + j] (a dense [k][n]
+    NNS_REFS_SOA = 64,   /* the reference points are given dimension-major, r[t * n + j] (a dense [k][n]
                           * array: the layout v4::mat_inv_kernel produces, core.cu:293-306, :327) instead
                           * of r[j * k + t]; queries stay [m][k].  The library transposes once on the
                           * device into a copy it owns. */
+    NNS_MULTI_FORCE_COLLECTIVE = 256 /* nns_search_*_multi, for tests: no single-GPU shortcut — even ONE shard runs the
+                          * thread-per-GPU body, ncclCommInitAll and the grouped ncclAllReduce (core.cu:965-1057's
+                          * shape), so that branch can be executed on a one-GPU box (a 1-rank all-reduce) */
 };
 
 /*
@@ -154,13 +166,18 @@ int nns_search_f32_ex(int k, int m, int n, const float *s_points,
  * is wrong for m > 1).  The RCCL communicators of a device set are created
  * on the first call and cached for the life of the process (nns_shutdown() destroys
  * them); concurrent multi calls of one process are serialised around the collective.
- * NNS_REFS_SOA is accepted (a shard is then a column range of the [k][n] array). */
+ * NNS_REFS_SOA is accepted (a shard is then a column range of the [k][n] array).  m or n above
+ * NNS_MAX_POINTS: NNS_ERR_INVALID, before anything is allocated.  The caller's current device is
+ * restored on return. */
 int nns_search_f32_multi(int k, int m, int n, const float *s_points,
                          const float *r_points, int *idx_out, float *dist_out,
                          int num_devices, unsigned flags);
 int nns_search_bf16_multi(int k, int m, int n, const uint16_t *s_points,
                           const uint16_t *r_points, int *idx_out, float *dist_out,
                           int num_devices, unsigned flags);
+/* Diagnostic: the number of ranks of the last grouped RCCL all-reduce an nns_search_*_multi call of this process
+ * completed (0: none yet, or the keys were merged through the host instead). */
+int nns_multi_last_exchange_ranks(void);
 
 /* ---- split API (device-resident buffers, caller's stream) ------------------ */
 

@@ -112,6 +112,9 @@ struct nns_index {
     bool searched = false;
     int last_m = 0;
     int last_path = NNS_PATH_EXACT;
+    // the stream the index last enqueued work on: destroy / workspace regrow / read-outs wait for (or free behind)
+    // THAT stream, never for the whole device
+    hipStream_t last_stream = nullptr;
 };
 
 static int ensure_device_ok(int device)
@@ -128,6 +131,23 @@ static int ensure_device_ok(int device)
     NNS_HIP(hipSetDevice(device));
     return NNS_OK;
 }
+
+extern "C++" {
+namespace nns {
+int order_after_default_stream(hipStream_t st)
+{
+    if (!st) return NNS_OK;   // same stream: already ordered
+    int dev = 0;
+    NNS_HIP(hipGetDevice(&dev));
+    static thread_local hipEvent_t evs[64] = {};   // one per device and host thread, never destroyed
+    if (dev < 0 || dev >= 64) return NNS_OK;
+    if (!evs[dev]) NNS_HIP(hipEventCreateWithFlags(&evs[dev], hipEventDisableTiming));
+    NNS_HIP(hipEventRecord(evs[dev], nullptr));
+    NNS_HIP(hipStreamWaitEvent(st, evs[dev], 0));
+    return NNS_OK;
+}
+}  // namespace nns
+}  // extern "C++"
 
 static int prep_refs(nns_index *ix, hipStream_t st)
 {
@@ -176,23 +196,14 @@ int nns_device_count(void)
 int nns_index_destroy(nns_index *ix)
 {
     if (!ix) return NNS_OK;
+    DeviceScope keep_device;
     (void)hipSetDevice(ix->device);
-    // workspaces go back to the pool, not to hipFree (which would wait for the device itself):
-    // make sure nothing still reads them
-    (void)hipDeviceSynchronize();
-    pool_free(ix->r_own);
-    pool_free(ix->rimg);
-    pool_free(ix->rnorm);
-    pool_free(ix->mean);
-    pool_free(ix->mean_ws);
-    pool_free(ix->scal);
-    pool_free(ix->qimg);
-    pool_free(ix->qnorm);
-    pool_free(ix->lists);
-    pool_free(ix->counts);
-    pool_free(ix->amb_list);
-    pool_free(ix->multi_list);
-    pool_free(ix->exact_ws);
+    // Workspaces go back to the pool behind ONE event on the stream the index last worked on: they become
+    // reusable when that work has completed.  No host wait — an application's kernels on other streams (or this
+    // index's own, still running) are not waited for.  (Round 2: hipDeviceSynchronize() here.)
+    void *const blocks[] = {ix->r_own, ix->rimg, ix->rnorm, ix->mean, ix->mean_ws, ix->scal, ix->qimg, ix->qnorm,
+                            ix->lists, ix->counts, ix->amb_list, ix->multi_list, ix->exact_ws};
+    pool_free_after(blocks, (int)(sizeof(blocks) / sizeof(blocks[0])), ix->last_stream);
     if (ix->ev_valid)
         for (int r = 0; r < kEvRing; ++r)
             for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ix->evr[r][i]);
@@ -229,6 +240,7 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
     ix->r_dev = r_dev;
     ix->bf16 = bf16;
     ix->profile = (flags & NNS_PROFILE) != 0;
+    ix->last_stream = st;
     if (flags & NNS_FILTER_BF16) {
         if (bf16) {
             set_error("NNS_FILTER_BF16 applies to fp32 points (bf16 points already use the bf16 filter)");
@@ -326,20 +338,24 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
 int nns_index_create(nns_index **out, int device, int k, int n, const float *r_dev, int64_t index_base,
                      unsigned flags, void *stream)
 {
+    DeviceScope keep_device;
     return index_create_impl(out, device, k, n, r_dev, 0, index_base, flags & ~kCreateNoSync, stream);
 }
 
 int nns_index_create_bf16(nns_index **out, int device, int k, int n, const uint16_t *r_dev,
                           int64_t index_base, unsigned flags, void *stream)
 {
+    DeviceScope keep_device;
     return index_create_impl(out, device, k, n, r_dev, 1, index_base, flags & ~kCreateNoSync, stream);
 }
 
 int nns_index_refresh(nns_index *ix, void *stream)
 {
     if (!ix) return NNS_ERR_INVALID;
+    DeviceScope keep_device;
     NNS_TRY(ensure_device_ok(ix->device));
     hipStream_t st = (hipStream_t)stream;
+    ix->last_stream = st;
     if (ix->r_soa)   // the caller's dimension-major array may have changed
         NNS_TRY(launch_soa_to_aos(ix->k, ix->n, ix->r_soa, ix->r_own, ix->bf16 ? 2 : 4, st));
     if (ix->path != NNS_PATH_MFMA) return NNS_OK;
@@ -356,7 +372,10 @@ int nns_index_refresh(nns_index *ix, void *stream)
     return NNS_OK;
 }
 
-static int ensure_query_ws(nns_index *ix, int m)
+// (a block that is replaced goes back to the pool behind an event on `st`, the stream of the search that is about
+//  to be enqueued: the index's earlier searches were ordered before it by the caller — searches of one index do
+//  not overlap — so once that event has fired nothing reads the old block any more.  No host wait.)
+static int ensure_query_ws(nns_index *ix, int m, hipStream_t st)
 {
     FilterGeom g = ix->geom;
     FilterGeom gq{};
@@ -364,11 +383,8 @@ static int ensure_query_ws(nns_index *ix, int m)
     ix->geom = gq;   // same kt / n_pad / total_slots; m-dependent grid now filled in
     (void)g;
     if (gq.m_pad > ix->m_cap) {
-        if (ix->qimg) (void)hipDeviceSynchronize();   // an earlier search may still read them
-        pool_free(ix->qimg);
-        pool_free(ix->qnorm);
-        pool_free(ix->amb_list);
-        pool_free(ix->multi_list);
+        void *const old[] = {ix->qimg, ix->qnorm, ix->amb_list, ix->multi_list};
+        pool_free_after(old, 4, st);   // an earlier search may still read them
         ix->qimg = nullptr;
         ix->qnorm = nullptr;
         ix->amb_list = nullptr;
@@ -385,9 +401,8 @@ static int ensure_query_ws(nns_index *ix, int m)
     }
     const size_t need = (size_t)gq.splits * gq.m_pad * gq.lpq;   // lane-lists
     if (need > ix->lists_cap) {
-        if (ix->lists) (void)hipDeviceSynchronize();
-        pool_free(ix->lists);
-        pool_free(ix->counts);
+        void *const old[] = {ix->lists, ix->counts};
+        pool_free_after(old, 2, st);
         ix->lists = nullptr;
         ix->counts = nullptr;
         ix->lists_cap = 0;
@@ -433,6 +448,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
     hipStream_t st = (hipStream_t)stream;
     const bool prof = ix->profile;
     ix->last_m = m;
+    ix->last_stream = st;
 
     // A handful of queries cannot fill MFMA tiles (they are padded to 256): the ref stream
     // is then HBM-bound and the exact lane-per-ref kernel is the faster path (AUTO only).
@@ -446,8 +462,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
         {
             const size_t need = exact_workspace_keys(ix->k, m, ix->n);
             if (need > ix->exact_ws_keys) {
-                if (ix->exact_ws) (void)hipDeviceSynchronize();
-                pool_free(ix->exact_ws);
+                pool_free_after(ix->exact_ws, st);
                 ix->exact_ws = nullptr;
                 ix->exact_ws_keys = 0;
                 if (pool_alloc(&ix->exact_ws, need * sizeof(nns_key)) == hipSuccess) {
@@ -473,7 +488,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
         return NNS_OK;
     }
 
-    NNS_TRY(ensure_query_ws(ix, m));
+    NNS_TRY(ensure_query_ws(ix, m, st));
     const FilterGeom &g = ix->geom;
     if (prof) (void)hipEventRecord(ix->evr[ix->ev_slot][EV_BEGIN], st);
     // reset the per-search scalars (q max-abs, ambiguous count); keep the ref-side ones
@@ -527,11 +542,13 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
 
 int nns_index_search(nns_index *ix, int m, const float *q_dev, nns_key *keys_dev, void *stream)
 {
+    DeviceScope keep_device;
     return index_search_impl(ix, m, q_dev, 0, keys_dev, stream);
 }
 
 int nns_index_search_bf16(nns_index *ix, int m, const uint16_t *q_dev, nns_key *keys_dev, void *stream)
 {
+    DeviceScope keep_device;
     return index_search_impl(ix, m, q_dev, 1, keys_dev, stream);
 }
 
@@ -542,12 +559,14 @@ int nns_index_search_indices(nns_index *ix, int m, const void *q_dev, nns_key *k
         set_error("nns_index_search_indices: idx_dev is null");
         return NNS_ERR_INVALID;
     }
+    DeviceScope keep_device;
     return index_search_impl(ix, m, q_dev, ix ? ix->bf16 : 0, keys_dev, stream, idx_dev, dist_dev);
 }
 
 int nns_index_stats(nns_index *ix, nns_stats *out)
 {
     if (!ix || !out) return NNS_ERR_INVALID;
+    DeviceScope keep_device;
     NNS_TRY(ensure_device_ok(ix->device));
     memset(out, 0, sizeof(*out));
     out->path = ix->searched ? ix->last_path : ix->path;
@@ -555,16 +574,17 @@ int nns_index_stats(nns_index *ix, nns_stats *out)
     if (ix->path == NNS_PATH_MFMA) {
         out->k_tile = ix->geom.kt;
         out->splits = ix->geom.splits;
-        NNS_HIP(hipDeviceSynchronize());
+        // (the index's own stream, not the device: the read-out waits for this index's work only)
         DevScalars h{};
-        NNS_HIP(hipMemcpy(&h, ix->scal, sizeof(h), hipMemcpyDeviceToHost));
+        NNS_HIP(hipMemcpyAsync(&h, ix->scal, sizeof(h), hipMemcpyDeviceToHost, ix->last_stream));
+        NNS_HIP(hipStreamSynchronize(ix->last_stream));
         out->ambiguous = ix->searched && ix->last_path == NNS_PATH_MFMA ? h.amb_count : 0;
         out->multi_candidate = ix->searched && ix->last_path == NNS_PATH_MFMA ? h.multi_count : 0;
         ix->refs_bad = h.r_maxabs_bits >= 0x5BB1A2BCu;   // (re-)latch: refs that void the bound go straight to K1
         if (ix->refs_bad || h.q_maxabs_bits >= 0x5BB1A2BCu) out->nonfinite = 1;
     }
     if (ix->profile && ix->ev_valid) {
-        NNS_HIP(hipDeviceSynchronize());
+        NNS_HIP(hipStreamSynchronize(ix->last_stream));
         // averages over the searches recorded since the previous call (the last kEvRing at most)
         const int cnt = ix->ev_count;
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // refs, qprep, filter, final, rerank, exact, total
@@ -620,14 +640,18 @@ int nns_index_near_ties(nns_index *ix, int *ids_out, int cap, int *count_out)
         return NNS_ERR_INVALID;
     }
     *count_out = 0;
+    DeviceScope keep_device;
     NNS_TRY(ensure_device_ok(ix->device));
     if (ix->path != NNS_PATH_MFMA || !ix->searched || ix->last_path != NNS_PATH_MFMA) return NNS_OK;
-    NNS_HIP(hipDeviceSynchronize());
     DevScalars h{};
-    NNS_HIP(hipMemcpy(&h, ix->scal, sizeof(h), hipMemcpyDeviceToHost));
+    NNS_HIP(hipMemcpyAsync(&h, ix->scal, sizeof(h), hipMemcpyDeviceToHost, ix->last_stream));
+    NNS_HIP(hipStreamSynchronize(ix->last_stream));
     *count_out = h.multi_count;
     const int take = h.multi_count < cap ? h.multi_count : cap;
-    if (take > 0) NNS_HIP(hipMemcpy(ids_out, ix->multi_list, (size_t)take * sizeof(int), hipMemcpyDeviceToHost));
+    if (take > 0) {
+        NNS_HIP(hipMemcpyAsync(ids_out, ix->multi_list, (size_t)take * sizeof(int), hipMemcpyDeviceToHost, ix->last_stream));
+        NNS_HIP(hipStreamSynchronize(ix->last_stream));
+    }
     return NNS_OK;
 }
 
@@ -663,6 +687,7 @@ int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const fl
 {
     if (kt <= 0 || (kt & 15) || (bf16 == 2 && (kt & 31)) || bf16 < 0 || bf16 > 2 || !a || !b || !c0 || !out)
         return NNS_ERR_INVALID;
+    DeviceScope keep_device;
     NNS_TRY(ensure_device_ok(0));
     float *d = nullptr;
     const size_t na = (size_t)32 * kt, total = 2 * na + 32 + 1024;
@@ -719,6 +744,7 @@ int nns_plan_filter(int k, int m, int n, int bf16_points, unsigned flags, int *o
 int nns_selftest_lane_share(int tile16, const float *in64, float *out64)
 {
     if (!in64 || !out64) return NNS_ERR_INVALID;
+    DeviceScope keep_device;
     NNS_TRY(ensure_device_ok(0));
     float *d = nullptr;
     NNS_HIP(pool_alloc(&d, 128 * sizeof(float)));
@@ -767,7 +793,9 @@ static int search_host_small(int k, int m, int n, const void *s_points, const vo
         set_error("nns_search_f32: device allocation failed");
         return NNS_ERR_NOMEM;
     }
-    hipStream_t st = nullptr;
+    // a non-blocking stream of the library: the legacy default stream would serialise with every blocking stream
+    // of the application (nullptr if none can be made: the default stream then)
+    hipStream_t st = lib_stream_acquire();
     nns_index *ix = nullptr;
     int rc = NNS_OK;
     do {
@@ -792,9 +820,11 @@ static int search_host_small(int k, int m, int n, const void *s_points, const vo
         memcpy(idx_out, host_out, (size_t)m * sizeof(int));
         if (dist_out) memcpy(dist_out, host_out + (off_dist - off_idx), (size_t)m * sizeof(float));
     } while (0);
-    if (ix) nns_index_destroy(ix);            // (synchronises)
-    else (void)hipDeviceSynchronize();        // the block goes back to the pool: nothing may still use it
-    pool_free(blk);
+    // (rc == NNS_OK: the stream was synchronised above and everything is reusable at once; on an error path the
+    //  blocks wait behind an event on the stream)
+    if (ix) nns_index_destroy(ix);
+    pool_free_after(blk, st);
+    lib_stream_release(st);
     return rc;
 }
 
@@ -837,10 +867,12 @@ static int search_range_overlapped_impl(int device, int k, int m, int n, const v
                                         int bf16, int64_t base, unsigned flags, nns_key *keys, nns_key *keys_tmp)
 {
     const size_t esz = bf16 ? sizeof(uint16_t) : sizeof(float);
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
-        (void)hipGetLastError();
-        return NNS_ERR_UNSUPPORTED;
+    hipStream_t st = lib_stream_acquire();
+    if (!st) return NNS_ERR_UNSUPPORTED;
+    // the caller's query upload (synchronous copy) happens before the first search
+    if (order_after_default_stream(st) != NNS_OK) {
+        lib_stream_release(st);
+        return NNS_ERR_HIP;
     }
     std::vector<nns_index *> shards;
     int rc = NNS_OK;
@@ -864,6 +896,9 @@ static int search_range_overlapped_impl(int device, int k, int m, int n, const v
             rc = NNS_ERR_HIP;
             break;
         }
+        // explicit edge copy -> this chunk's kernels (an event on the default stream: it does not wait for the
+        // previous chunk's search, which runs on the non-blocking stream)
+        if ((rc = order_after_default_stream(st)) != NNS_OK) break;
         nns_index *ix = nullptr;
         rc = index_create_impl(&ix, device, k, cnt, r_d + (size_t)beg * k * esz, bf16, base + beg, flags | kCreateNoSync, st);
         if (rc != NNS_OK) break;
@@ -874,9 +909,9 @@ static int search_range_overlapped_impl(int device, int k, int m, int n, const v
     }
     if (rc == NNS_OK && hipStreamSynchronize(st) != hipSuccess) rc = NNS_ERR_HIP;
     if (rc == NNS_ERR_HIP) set_error("nns_search (chunked upload): %s", hipGetErrorString(hipGetLastError()));
-    (void)hipDeviceSynchronize();   // the shards' workspaces go back to the pool: nothing may still use them
-    for (nns_index *ix : shards) nns_index_destroy(ix);
-    (void)hipStreamDestroy(st);
+    if (rc != NNS_OK) (void)hipStreamSynchronize(st);   // error paths: the caller frees r_d / keys right away
+    for (nns_index *ix : shards) nns_index_destroy(ix);   // (workspaces: behind an event on st)
+    lib_stream_release(st);
     return rc;
 }
 
@@ -922,7 +957,10 @@ static int search_host_chunked(int k, int m, int n, const void *s_points, const 
             break;
         }
         rc = search_range_overlapped_impl(device, k, m, n, q_d, r_points, r_d, bf16, 0, flags, keys, keys_tmp);
-        if (rc != NNS_OK) break;      // (UNSUPPORTED: no stream — the caller takes the plain path)
+        // (UNSUPPORTED: no stream — the caller takes the plain path; NOMEM likewise: the four chunk indexes carry
+        //  four query-side workspaces, the plain single-index path may still fit)
+        if (rc == NNS_ERR_NOMEM) rc = NNS_ERR_UNSUPPORTED;
+        if (rc != NNS_OK) break;
         rc = nns_keys_unpack(keys, m, idx_d, dist_d, nullptr);
         if (rc != NNS_OK) break;
         if (hipMemcpy(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
@@ -931,7 +969,8 @@ static int search_host_chunked(int k, int m, int n, const void *s_points, const 
             rc = NNS_ERR_HIP;
         }
     } while (0);
-    (void)hipDeviceSynchronize();   // the blocks go back to the pool: nothing may still use them
+    // (the overlapped core has waited for its stream; unpack + the synchronous downloads ran on the default stream)
+    if (rc != NNS_OK) (void)hipStreamSynchronize(nullptr);
     pool_free(q_d);
     pool_free(r_d);
     pool_free(keys);
@@ -957,6 +996,7 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
         set_error("nns_search_f32: point set too large for one call");
         return NNS_ERR_INVALID;
     }
+    DeviceScope keep_device;
     NNS_TRY(ensure_device_ok(device));
     if (num_shards < 1) num_shards = 1;
     if (num_shards > n) num_shards = n;   // the reference clamps GPUs to n (core.cu:771-772)
@@ -974,7 +1014,9 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
     float *dist_d = nullptr;
     nns_key *keys = nullptr, *keys_tmp = nullptr;
     int *idx_d = nullptr;
-    hipStream_t st = nullptr;
+    // kernels on a non-blocking stream of the library (nullptr if none can be made: the default stream then);
+    // the synchronous copies stay on the default stream, with explicit event edges in between
+    hipStream_t st = lib_stream_acquire();
     int rc = NNS_OK;
     nns_index *ix = nullptr;
     do {
@@ -994,6 +1036,7 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             rc = NNS_ERR_HIP;
             break;
         }
+        if ((rc = order_after_default_stream(st)) != NNS_OK) break;   // uploads -> kernels
         if (flags & NNS_REFS_SOA) {
             // dimension-major refs: transpose once on the device, then shard the point-major copy
             if (pool_alloc(&r_t, rb) != hipSuccess) {
@@ -1029,7 +1072,10 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             first = false;
         }
         if (rc != NNS_OK) break;
-        if (num_shards > 1) rc = nns_keys_unpack(keys, m, idx_d, dist_d, st);
+        if (num_shards > 1) {
+            rc = nns_keys_unpack(keys, m, idx_d, dist_d, st);
+            if (rc == NNS_OK && hipStreamSynchronize(st) != hipSuccess) rc = NNS_ERR_HIP;
+        }
         if (rc != NNS_OK) break;
         if (hipMemcpy(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
             (dist_out && hipMemcpy(dist_out, dist_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
@@ -1037,14 +1083,12 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             rc = NNS_ERR_HIP;
         }
     } while (0);
-    (void)hipDeviceSynchronize();   // the blocks go back to the pool: nothing may still use them
-    pool_free(q_d);
-    pool_free(r_d);
-    pool_free(r_t);
-    pool_free(keys);
-    pool_free(keys_tmp);
-    pool_free(idx_d);
-    pool_free(dist_d);
+    // success: every shard's stream work was waited for above; error paths: behind an event on the stream
+    if (ix) nns_index_destroy(ix);
+    void *const blocks[] = {q_d, r_d, r_t, keys, keys_tmp, idx_d, dist_d};
+    if (rc == NNS_OK) for (void *b : blocks) pool_free(b);
+    else pool_free_after(blocks, 7, st);
+    lib_stream_release(st);
     return rc;
 }
 
@@ -1062,6 +1106,7 @@ int nns_search_bf16_ex(int k, int m, int n, const uint16_t *s_points, const uint
 
 int nns_warmup(int device)
 {
+    DeviceScope keep_device;
     NNS_TRY(ensure_device_ok(device));
     // (k, m, n, bf16, path): K1a (3-D and 16-D), K1b, the fp32 tile depths 16 / 32 / 64 / 128 / 256 (forced onto the
     // filter: AUTO keeps a 64 x 512 x 16 problem on the exact kernel), the bf16-operand tiles for fp32 points (512 /

@@ -12,7 +12,9 @@
 // It adds an FNV-1a digest of the result indices per sample so a run can be compared with
 // the oracle's digests (tests/test_driver.py) — the driver itself contains no CPU search.
 //
-// usage: nns_driver [--seed S] [--samples a,b,...] [--repeat R] [--no-warmup] [--all-gpus]
+// usage: nns_driver [--seed S] [--samples a,b,...] [--shape k,m,n] [--repeat R] [--no-warmup] [--all-gpus]
+//   --shape: ONE shape of the caller's choice instead of the table, drawn from the same recipe (srand(seed), queries
+//   first, refs second) — e.g. BASELINE's C1, 1024 x 4096 x 3: --shape 3,1024,4096
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -72,6 +74,7 @@ int main(int argc, char **argv)
     bool warmup = true;
     bool all_gpus = false;   // mi355x::cudaCallAllGpus (the V8/V9 analogue) instead of one GPU
     bool selected[kNumShapes];
+    Shape custom = {0, 0, 0};
     for (int i = 0; i < kNumShapes; ++i) selected[i] = true;
     for (int a = 1; a < argc; ++a) {
         if (!strcmp(argv[a], "--seed") && a + 1 < argc) seed = (unsigned)strtoul(argv[++a], nullptr, 10);
@@ -86,8 +89,11 @@ int main(int argc, char **argv)
                 if (i >= 0 && i < kNumShapes) selected[i] = true;
                 tok = strtok(nullptr, ",");
             }
+        } else if (!strcmp(argv[a], "--shape") && a + 1 < argc && sscanf(argv[a + 1], "%d,%d,%d", &custom.k, &custom.m, &custom.n) == 3 &&
+                   custom.k > 0 && custom.m > 0 && custom.n > 0) {
+            ++a;
         } else {
-            fprintf(stderr, "usage: %s [--seed S] [--samples a,b,...] [--repeat R] [--no-warmup] [--all-gpus]\n", argv[0]);
+            fprintf(stderr, "usage: %s [--seed S] [--samples a,b,...] [--shape k,m,n] [--repeat R] [--no-warmup] [--all-gpus]\n", argv[0]);
             return 2;
         }
     }
@@ -106,12 +112,13 @@ int main(int argc, char **argv)
     const int v = 100;   // version tag printed where the reference prints v = 0..13
     printf("\nRunning CUDACALL %d (mi355x::cudaCall)...\n", v);
     srand(seed);   // once, before the table (main.cu:64)
-    for (int i = 0; i < kNumShapes; ++i) {
-        const Shape s = kShapes[i];
+    const int nshapes = custom.k ? 1 : kNumShapes;
+    for (int i = 0; i < nshapes; ++i) {
+        const Shape s = custom.k ? custom : kShapes[i];
         // the stream is consumed in table order even for samples that are skipped
         float *s_points = draw((size_t)s.k * s.m);
         float *r_points = draw((size_t)s.k * s.n);
-        if (selected[i]) {
+        if (custom.k || selected[i]) {
             for (int rep = 0; rep < repeat; ++rep) {
                 int *results = nullptr;
                 const long st = now_ns();

@@ -33,7 +33,38 @@ void set_error(const char *fmt, ...);
 hipError_t pool_alloc(void **out, size_t bytes);
 template <class T> static inline hipError_t pool_alloc(T **out, size_t bytes) { return pool_alloc((void **)out, bytes); }
 void pool_free(void *ptr);     // caller has synchronised the work that used ptr
+// ptr may still be in use by work already enqueued on `st`: reusable once an event recorded there has fired (no host wait)
+void pool_free_after(void *ptr, hipStream_t st);
+void pool_free_after(void *const *ptrs, int count, hipStream_t st);   // one event for all of them; nulls skipped
 size_t pool_trim();            // give every parked block back to the runtime
+// the library's own non-blocking streams (whole-call entry points); nullptr if none can be created
+hipStream_t lib_stream_acquire();
+void lib_stream_release(hipStream_t s);
+
+// Every C-ABI entry point that selects a device restores the caller's current device on return (the reference's
+// V8/V9 leave whatever cudaSetDevice they called last, core.cu:996; a library must not).
+struct DeviceScope {
+    int saved = -1;
+    DeviceScope()
+    {
+        if (hipGetDevice(&saved) != hipSuccess) {
+            (void)hipGetLastError();
+            saved = -1;
+        }
+    }
+    ~DeviceScope()
+    {
+        int cur = -1;
+        if (saved >= 0 && hipGetDevice(&cur) == hipSuccess && cur != saved) (void)hipSetDevice(saved);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
+// "the H2D copy that just returned (synchronous, legacy default stream) happens before whatever is enqueued on
+// `st` next": an explicit event edge.  This runtime's pageable hipMemcpy returns after the device-side DMA, so the
+// edge is already true here; CUDA documents the opposite for pageable sources and nothing in HIP's API promises it.
+int order_after_default_stream(hipStream_t st);
 void stager_release();         // free the small whole calls' pinned scratch (nns_api.hip)
 // the overlapped upload of a contiguous host ref range (nns_api.hip), shared with nns_search_*_multi's shards
 bool upload_overlap_pays(int k, int64_t m, int64_t n, int bf16, unsigned flags, size_t rbytes);

@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -101,6 +102,10 @@ struct CommCache {
     std::mutex mu;   // held over create AND over the collective: one multi call at a time per process
     std::map<std::vector<int>, CommSet> sets;
 };
+// ranks of the last grouped all-reduce that completed (0: none yet, or it failed): lets a test see that the
+// collective branch really ran (nns_multi_last_exchange_ranks)
+static std::atomic<int> g_last_exchange_ranks{0};
+
 static CommCache &comm_cache()
 {
     static CommCache *c = new CommCache();   // leaked on purpose (no destructor order games at exit)
@@ -112,6 +117,7 @@ struct ShardJob {
     int beg = 0, cnt = 0;
     char *q_d = nullptr, *r_d = nullptr;
     nns_key *keys = nullptr;
+    hipStream_t st = nullptr;   // the shard's non-blocking stream: search, exchange and unpack are enqueued here
     int rc = NNS_OK;
     char err[256] = "";
 };
@@ -123,7 +129,8 @@ static void run_shard(ShardJob *job, int k, int m, int n, const void *q, const v
         job->rc = rc;
         snprintf(job->err, sizeof(job->err), "device %d: %s (%s)", job->device, what, nns_last_error());
     };
-    if (hipSetDevice(job->device) != hipSuccess) return fail(NNS_ERR_HIP, "hipSetDevice");
+    if (hipSetDevice(job->device) != hipSuccess) return fail(NNS_ERR_HIP, "hipSetDevice");   // (this thread's device)
+    job->st = lib_stream_acquire();   // (nullptr: the default stream)
     const size_t esz = bf16 ? sizeof(uint16_t) : sizeof(float);
     const size_t qb = (size_t)m * k * esz, rb = (size_t)job->cnt * k * esz;
     if (pool_alloc(&job->q_d, qb) != hipSuccess || pool_alloc(&job->r_d, rb) != hipSuccess ||
@@ -141,22 +148,23 @@ static void run_shard(ShardJob *job, int k, int m, int n, const void *q, const v
         if (pool_alloc(&tmp, (size_t)m * sizeof(nns_key)) != hipSuccess) return fail(NNS_ERR_NOMEM, "device allocation");
         const int orc = search_range_overlapped(job->device, k, m, job->cnt, job->q_d, (const char *)r + (size_t)job->beg * k * esz,
                                                 job->r_d, bf16, job->beg, flags, job->keys, tmp);
-        (void)hipDeviceSynchronize();
-        pool_free(tmp);
+        pool_free(tmp);   // (the overlapped core returns with its stream waited for)
         if (orc == NNS_OK) return;
-        if (orc != NNS_ERR_UNSUPPORTED) return fail(orc, "search (overlapped upload)");
+        // (NOMEM: four chunk indexes carry four query-side workspaces; the plain single-index path may still fit)
+        if (orc != NNS_ERR_UNSUPPORTED && orc != NNS_ERR_NOMEM) return fail(orc, "search (overlapped upload)");
         up = hipMemcpy(job->r_d, (const char *)r + (size_t)job->beg * k * esz, rb, hipMemcpyHostToDevice) == hipSuccess;
     } else {
         up = up && hipMemcpy(job->r_d, (const char *)r + (size_t)job->beg * k * esz, rb, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!up) return fail(NNS_ERR_HIP, "H2D copy");
+    if (order_after_default_stream(job->st) != NNS_OK) return fail(NNS_ERR_HIP, "event edge upload -> search");
     nns_index *ix = nullptr;
-    int rc = bf16 ? nns_index_create_bf16(&ix, job->device, k, job->cnt, (const uint16_t *)job->r_d, job->beg, flags, nullptr)
-                  : nns_index_create(&ix, job->device, k, job->cnt, (const float *)job->r_d, job->beg, flags, nullptr);
+    int rc = bf16 ? nns_index_create_bf16(&ix, job->device, k, job->cnt, (const uint16_t *)job->r_d, job->beg, flags, job->st)
+                  : nns_index_create(&ix, job->device, k, job->cnt, (const float *)job->r_d, job->beg, flags, job->st);
     if (rc == NNS_OK)
-        rc = bf16 ? nns_index_search_bf16(ix, m, (const uint16_t *)job->q_d, job->keys, nullptr)
-                  : nns_index_search(ix, m, (const float *)job->q_d, job->keys, nullptr);
-    if (rc == NNS_OK && hipDeviceSynchronize() != hipSuccess) rc = NNS_ERR_HIP;
+        rc = bf16 ? nns_index_search_bf16(ix, m, (const uint16_t *)job->q_d, job->keys, job->st)
+                  : nns_index_search(ix, m, (const float *)job->q_d, job->keys, job->st);
+    if (rc == NNS_OK && hipStreamSynchronize(job->st) != hipSuccess) rc = NNS_ERR_HIP;
     nns_index_destroy(ix);
     if (rc != NNS_OK) fail(rc, "search");
 }
@@ -168,6 +176,16 @@ static int search_multi_impl(int k, int m, int n, const void *s_points, const vo
         set_error("nns_search_multi: k, m, n must be > 0 and pointers non-null");
         return NNS_ERR_INVALID;
     }
+    // the same limits as the single-device entry points (nns.h), before any thread or allocation
+    if (m > NNS_MAX_POINTS || n > NNS_MAX_POINTS) {
+        set_error("nns_search_multi: m = %d / n = %d exceeds NNS_MAX_POINTS (%d)", m, n, NNS_MAX_POINTS);
+        return NNS_ERR_INVALID;
+    }
+    if ((int64_t)k * m > 0x7FFFFFFFll * 4 || (int64_t)k * n > 0x7FFFFFFFll * 4) {
+        set_error("nns_search_multi: point set too large for one call");
+        return NNS_ERR_INVALID;
+    }
+    DeviceScope keep_device;   // the caller's current device is restored on every return path
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) {
         set_error("no HIP device visible (the HIP path has no CPU fallback)");
@@ -177,12 +195,15 @@ static int search_multi_impl(int k, int m, int n, const void *s_points, const vo
     // NNS_MULTI_VIRTUAL: rehearsal on fewer GPUs than shards — shard g runs on device
     // g % visible (several host threads per device) and the keys merge through the host
     const bool virt = (flags & NNS_MULTI_VIRTUAL) != 0;
-    flags &= ~(unsigned)NNS_MULTI_VIRTUAL;
+    // NNS_MULTI_FORCE_COLLECTIVE (tests): no single-GPU shortcut — also ONE shard goes through the thread-per-GPU
+    // body, ncclCommInitAll and the grouped all-reduce, so that branch runs on a one-GPU box too
+    const bool force = (flags & NNS_MULTI_FORCE_COLLECTIVE) != 0;
+    flags &= ~(unsigned)(NNS_MULTI_VIRTUAL | NNS_MULTI_FORCE_COLLECTIVE);
     if (G > visible && !virt) G = visible;
     if (G > n) G = n;                                   // core.cu:771-772
     // the reference keeps small problems on one GPU (core.cu:775-777)
     const int64_t small_n = ((int64_t)m << 10) < (1 << 18) ? ((int64_t)m << 10) : (1 << 18);
-    if (G == 1 || (!virt && n <= small_n))
+    if (!force && (G == 1 || (!virt && n <= small_n)))
         return bf16 ? nns_search_bf16_ex(k, m, n, (const uint16_t *)s_points, (const uint16_t *)r_points, idx_out, dist_out, 1, flags, 0)
                     : nns_search_f32_ex(k, m, n, (const float *)s_points, (const float *)r_points, idx_out, dist_out, 1, flags, 0);
 
@@ -214,7 +235,7 @@ static int search_multi_impl(int k, int m, int n, const void *s_points, const vo
 
     // ---- the exchange: one min all-reduce of the packed keys ----------------------------
     bool reduced = false;
-    if (rc == NNS_OK && G > 1 && G <= visible) {   // distinct devices only: RCCL rejects duplicates
+    if (rc == NNS_OK && (G > 1 || force) && G <= visible) {   // distinct devices only: RCCL rejects duplicates
         const RcclApi &api = rccl();
         if (api.ok) {
             std::vector<int> devs(G);
@@ -231,13 +252,14 @@ static int search_multi_impl(int k, int m, int n, const void *s_points, const vo
                 const std::vector<ncclComm_t> &comms = it->second.comms;
                 bool ok = api.GroupStart() == ncclSuccess;
                 for (int g = 0; g < G && ok; ++g)
-                    ok = hipSetDevice(jobs[g].device) == hipSuccess && allreduce_min(jobs[g].keys, m, comms[g], nullptr) == ncclSuccess;
+                    ok = hipSetDevice(jobs[g].device) == hipSuccess && allreduce_min(jobs[g].keys, m, comms[g], jobs[g].st) == ncclSuccess;
                 ok = (api.GroupEnd() == ncclSuccess) && ok;
                 for (int g = 0; g < G; ++g) {
                     (void)hipSetDevice(jobs[g].device);
-                    if (hipDeviceSynchronize() != hipSuccess) ok = false;
+                    if (hipStreamSynchronize(jobs[g].st) != hipSuccess) ok = false;
                 }
                 reduced = ok;
+                g_last_exchange_ranks.store(ok ? G : 0, std::memory_order_relaxed);
                 if (!ok) {   // a failed collective leaves the communicators in an unknown state: drop them
                     for (ncclComm_t c : comms) (void)api.CommDestroy(c);
                     cc.sets.erase(it);
@@ -270,25 +292,25 @@ static int search_multi_impl(int k, int m, int n, const void *s_points, const vo
         if (rc == NNS_OK && (pool_alloc(&idx_d, (size_t)m * sizeof(int)) != hipSuccess ||
                              pool_alloc(&dist_d, (size_t)m * sizeof(float)) != hipSuccess))
             rc = NNS_ERR_NOMEM;
-        if (rc == NNS_OK) rc = nns_keys_unpack(jobs[0].keys, m, idx_d, dist_d, nullptr);
+        if (rc == NNS_OK) rc = order_after_default_stream(jobs[0].st);   // (the host-merge upload above, if any)
+        if (rc == NNS_OK) rc = nns_keys_unpack(jobs[0].keys, m, idx_d, dist_d, jobs[0].st);
+        if (rc == NNS_OK && hipStreamSynchronize(jobs[0].st) != hipSuccess) rc = NNS_ERR_HIP;
         if (rc == NNS_OK &&
             (hipMemcpy(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
              (dist_out && hipMemcpy(dist_out, dist_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)))
             rc = NNS_ERR_HIP;
-        (void)hipDeviceSynchronize();
-        pool_free(idx_d);
-        pool_free(dist_d);
+        void *const outs[] = {idx_d, dist_d};
+        pool_free_after(outs, 2, jobs[0].st);
         if (rc == NNS_ERR_HIP) set_error("nns_search_multi: merge/unpack failed: %s", hipGetErrorString(hipGetLastError()));
     }
     for (int g = 0; g < G; ++g) {
         (void)hipSetDevice(jobs[g].device);
-        (void)hipDeviceSynchronize();   // the blocks go back to the pool: nothing may still use them
-        pool_free(jobs[g].q_d);
-        pool_free(jobs[g].r_d);
-        pool_free(jobs[g].keys);
+        // the blocks go back to the pool behind an event on the shard's stream (no device-wide wait)
+        void *const blocks[] = {jobs[g].q_d, jobs[g].r_d, jobs[g].keys};
+        pool_free_after(blocks, 3, jobs[g].st);
+        lib_stream_release(jobs[g].st);
     }
-    (void)hipSetDevice(0);
-    return rc;
+    return rc;   // (keep_device restores the caller's device: round 2 left device 0 selected)
 }
 
 }  // namespace nns
@@ -299,6 +321,8 @@ using namespace nns;
 struct nns_comm {
     ncclComm_t comm = nullptr;
     int device = 0, nranks = 0, rank = 0;
+    hipStream_t last_stream = nullptr;   // of the last all-reduce: destroy waits for that stream, not for the device
+    bool used = false;
 };
 
 extern "C" {
@@ -358,6 +382,7 @@ int nns_comm_create(nns_comm **out, const void *id, size_t id_bytes, int nranks,
         set_error("nns_comm_create: device %d out of range (%d visible)", device, cnt);
         return NNS_ERR_INVALID;
     }
+    DeviceScope keep_device;
     NNS_HIP(hipSetDevice(device));
     ncclUniqueId uid;
     memcpy(&uid, id, NNS_COMM_ID_BYTES);
@@ -390,7 +415,10 @@ int nns_comm_allreduce_min(nns_comm *c, nns_key *keys_dev, int m, void *stream)
         set_error("nns_comm_allreduce_min: bad arguments");
         return NNS_ERR_INVALID;
     }
+    DeviceScope keep_device;
     NNS_HIP(hipSetDevice(c->device));
+    c->last_stream = (hipStream_t)stream;
+    c->used = true;
     const ncclResult_t r = allreduce_min(keys_dev, m, c->comm, (hipStream_t)stream);
     if (r != ncclSuccess) {
         set_error("ncclAllReduce(uint64, min, %d keys): %s", m, rccl_err(r));
@@ -402,15 +430,22 @@ int nns_comm_allreduce_min(nns_comm *c, nns_key *keys_dev, int m, void *stream)
 int nns_comm_destroy(nns_comm *c)
 {
     if (!c) return NNS_OK;
+    DeviceScope keep_device;
     (void)hipSetDevice(c->device);
-    (void)hipDeviceSynchronize();
+    if (c->used && hipStreamSynchronize(c->last_stream) != hipSuccess) {   // its last collective, not the device
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();   // (the stream is gone: the blunt way)
+    }
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     delete c;
     return NNS_OK;
 }
 
+int nns_multi_last_exchange_ranks(void) { return g_last_exchange_ranks.load(std::memory_order_relaxed); }
+
 int nns_shutdown(void)
 {
+    DeviceScope keep_device;
     {
         CommCache &cc = comm_cache();
         std::lock_guard<std::mutex> lk(cc.mu);

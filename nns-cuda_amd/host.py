@@ -28,6 +28,7 @@ LIB_PATH = os.environ.get("NNS_LIB_PATH") or os.path.join(_HERE, "libnns_mi355x.
 NNS_OK = 0
 NNS_PATH_AUTO, NNS_PATH_EXACT, NNS_PATH_MFMA, NNS_PROFILE, NNS_MULTI_VIRTUAL, NNS_REFS_SOA = 0, 1, 2, 16, 32, 64
 NNS_FILTER_BF16 = 128
+NNS_MULTI_FORCE_COLLECTIVE = 256
 NNS_KEY_NONE = 0x7F80000000000000
 
 _PATHS = {"auto": NNS_PATH_AUTO, "exact": NNS_PATH_EXACT, "mfma": NNS_PATH_MFMA}
@@ -42,6 +43,7 @@ ABI_SYMBOLS = (
     "nns_trim", "nns_warmup", "nns_shutdown", "nns_search_bf16_multi",
     "nns_index_near_ties", "nns_tau_consts", "nns_index_search_indices", "nns_selftest_lane_share", "nns_plan_filter",
     "nns_comm_unique_id", "nns_comm_create", "nns_comm_size", "nns_comm_allreduce_min", "nns_comm_destroy",
+    "nns_multi_last_exchange_ranks",
 )
 NNS_COMM_ID_BYTES = 128
 
@@ -96,6 +98,7 @@ def _load() -> ctypes.CDLL:
     lib.nns_comm_allreduce_min.argtypes = [c_vp, c_vp, c_int, c_vp]
     lib.nns_comm_destroy.argtypes = [c_vp]
     lib.nns_shutdown.argtypes = []
+    lib.nns_multi_last_exchange_ranks.argtypes = []
     lib.nns_index_destroy.argtypes = [c_vp]
     lib.nns_index_refresh.argtypes = [c_vp, c_vp]
     lib.nns_index_search.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
@@ -225,11 +228,14 @@ def search(query_points, reference_points, *, return_distances: bool = False, sh
 
 
 def search_multi(query_points, reference_points, *, num_devices: int = 0, return_distances: bool = False,
-                 path: str = "auto", virtual: bool = False, refs_soa: bool = False, bf16: bool = False):
+                 path: str = "auto", virtual: bool = False, refs_soa: bool = False, bf16: bool = False,
+                 force_collective: bool = False):
     """The V8/V9 analogue: refs sharded over `num_devices` GPUs of this process (0 = all),
     per-GPU keys combined with one RCCL min all-reduce.  `virtual` lets a 1-GPU box rehearse
     more shards than it has GPUs (host-side key merge).  `bf16`: the arrays hold bf16 bit
-    patterns (uint16); `refs_soa`: reference_points is dimension-major [k][n]."""
+    patterns (uint16); `refs_soa`: reference_points is dimension-major [k][n].  `force_collective`
+    (tests): no single-GPU shortcut, so that ncclCommInitAll + the grouped all-reduce also run with one
+    shard on a one-GPU box (NNS_MULTI_FORCE_COLLECTIVE)."""
     if bf16:
         q = np.ascontiguousarray(query_points, dtype=np.uint16)
         r = np.ascontiguousarray(reference_points, dtype=np.uint16)
@@ -244,7 +250,8 @@ def search_multi(query_points, reference_points, *, num_devices: int = 0, return
     n = r.shape[1] if refs_soa else r.shape[0]
     idx = np.empty(m, dtype=np.int32)
     dist = np.empty(m, dtype=np.float32) if return_distances else None
-    flags = _PATHS[path] | (NNS_MULTI_VIRTUAL if virtual else 0) | (NNS_REFS_SOA if refs_soa else 0)
+    flags = _PATHS[path] | (NNS_MULTI_VIRTUAL if virtual else 0) | (NNS_REFS_SOA if refs_soa else 0) \
+        | (NNS_MULTI_FORCE_COLLECTIVE if force_collective else 0)
     fn = lib.nns_search_bf16_multi if bf16 else lib.nns_search_f32_multi
     _check(fn(k, m, n, q.ctypes.data, r.ctypes.data, idx.ctypes.data,
               dist.ctypes.data if dist is not None else None, num_devices, flags), "nns_search_multi")
@@ -451,6 +458,11 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def multi_last_exchange_ranks() -> int:
+    """Ranks of the last grouped RCCL all-reduce a search_multi call completed (0: none / host merge)."""
+    return int(lib.nns_multi_last_exchange_ranks())
 
 
 def shutdown() -> None:

@@ -46,6 +46,11 @@ def test_argument_validation_returns_status_not_exit(pkg):
     idx = np.zeros(4, np.int32)
     assert pkg.lib.nns_search_f32_ex(1, 4, 0x7FF00001, q.ctypes.data, q.ctypes.data, idx.ctypes.data, None, 1, 0, 0) == 1
     assert b"NNS_MAX_POINTS" in pkg.lib.nns_last_error()
+    # the multi-GPU entry points apply the same limits, before any thread or allocation
+    assert pkg.lib.nns_search_f32_multi(1, 4, 0x7FF00001, q.ctypes.data, q.ctypes.data, idx.ctypes.data, None, 0, 0) == 1
+    assert b"NNS_MAX_POINTS" in pkg.lib.nns_last_error()
+    assert pkg.lib.nns_search_bf16_multi(1, 0x7FF00001, 4, q.ctypes.data, q.ctypes.data, idx.ctypes.data, None, 0, 0) == 1
+    assert pkg.lib.nns_search_f32_multi(3, 0, 4, q.ctypes.data, q.ctypes.data, idx.ctypes.data, None, 0, 0) == 1
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device error path")
@@ -69,8 +74,24 @@ def test_shipped_library_has_no_diagnostic_switches(pkg):
     # the only environment variable the library reads: the pool cap
     # (other NNS_* strings are names of include/nns.h flags quoted in error messages)
     names = {n for n in re.findall(rb"NNS_[A-Z_]{3,}", blob)
-             if not re.match(rb"NNS_(PATH_|FILTER_BF|REFS_SOA|COMM_ID_BYTES|MULTI_VIRTUAL|ERR_|KEY_NONE|MAX_POINTS)", n)}
+             if not re.match(rb"NNS_(PATH_|FILTER_BF|REFS_SOA|COMM_ID_BYTES|MULTI_VIRTUAL|MULTI_FORCE_COLLECTIVE|ERR_|KEY_NONE|MAX_POINTS)", n)}
     assert names == {b"NNS_POOL_BYTES"}, names
+
+
+def test_no_device_wide_synchronisation_in_the_product():
+    """Library manners: destroy / workspace regrow / whole-call exits free behind stream events (dev_pool.hip), read-outs
+    wait for the index's stream.  hipDeviceSynchronize() may only appear as the documented last resort when a stream
+    handle has already been destroyed by its owner, and hipSetDevice(0) never as an exit path."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "nns-cuda_amd", "csrc")
+    allowed = {"dev_pool.hip": 1, "nns_multi.hip": 1}      # pool_free_after's and nns_comm_destroy's fallbacks
+    for f in sorted(os.listdir(src)):
+        if not f.endswith((".hip", ".h", ".hpp", ".cpp")):
+            continue
+        text = open(os.path.join(src, f)).read()
+        code = re.sub(r"//[^\n]*", "", text)
+        assert code.count("hipDeviceSynchronize(") <= allowed.get(f, 0), f
+        assert "hipSetDevice(0)" not in code, f
 
 
 def test_shard_range_is_reference_split(pkg):

@@ -1522,3 +1522,103 @@ def test_deep_tile_specials_and_whole_call_bf16_pipeline(pkg, orc):
     want_idx, want_dist = orc.v0_search(q, r, threads=16)
     idx, dist = pkg.search_bf16(pkg.to_bf16_bits(q), pkg.to_bf16_bits(r), return_distances=True)
     assert np.array_equal(idx, want_idx) and np.array_equal(_bits(dist), _bits(want_dist))
+
+
+def test_grouped_rccl_all_reduce_runs_with_one_rank(pkg, orc):
+    """nns_search_*_multi's collective branch — ncclCommInitAll over the device list, ncclGroupStart / one
+    ncclAllReduce(uint64, min) per device on its own stream / ncclGroupEnd (the V8/V9 shape, core.cu:965-1057) — with
+    NNS_MULTI_FORCE_COLLECTIVE: no single-GPU shortcut, so the branch executes on a one-GPU box as a 1-rank group.
+    (Among >= 2 ranks it first runs in the driver's multi-GPU bench.)"""
+    rng = np.random.default_rng(57)
+    for (m, n, k, bf16) in [(300, 40000, 128, False), (1000, 300000, 3, False), (130, 9000, 256, True)]:
+        q = rng.random((m, k), dtype=np.float32)
+        r = rng.random((n, k), dtype=np.float32)
+        r[n - 1] = r[0]
+        q[0] = r[0]
+        if bf16:
+            q, r = orc.round_bf16(q), orc.round_bf16(r)
+        want_idx, want_dist = orc.v0_search(q, r, threads=8)
+        qa, ra = (pkg.to_bf16_bits(q), pkg.to_bf16_bits(r)) if bf16 else (q, r)
+        for rep in range(2):               # second call: the cached communicator
+            idx, dist = pkg.search_multi(qa, ra, num_devices=1, return_distances=True, force_collective=True, bf16=bf16)
+            assert pkg.multi_last_exchange_ranks() == 1          # the grouped all-reduce completed, on 1 rank
+            assert np.array_equal(idx, want_idx)
+            assert np.array_equal(_bits(dist), _bits(want_dist))
+    pkg.shutdown()                         # destroys the cached communicator
+    idx = pkg.search_multi(qa, ra, num_devices=1, force_collective=True, bf16=True)       # and builds a new one
+    assert np.array_equal(idx, want_idx) and pkg.multi_last_exchange_ranks() == 1
+
+
+def test_library_never_waits_for_foreign_streams(pkg, orc):
+    """Library manners: a long kernel the APPLICATION has running on another (non-blocking) stream must still be
+    running when index destroy / workspace regrow / stats read-outs / whole calls of every size class return —
+    none of them may synchronise the device (round 2: 17 hipDeviceSynchronize() calls on those paths)."""
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(58)
+    small = (rng.random((64, 16), dtype=np.float32), rng.random((1024, 16), dtype=np.float32))      # pinned-scratch path
+    mid = (rng.random((300, 64), dtype=np.float32), rng.random((20000, 64), dtype=np.float32))      # plain path (> 2 MiB)
+    big = (rng.random((2048, 128), dtype=np.float32), rng.random((65536, 128), dtype=np.float32))   # chunked upload
+    wants = [orc.v0_search(q, r, threads=8)[0] for q, r in (small, mid, big)]
+    qd, rd = torch.from_numpy(mid[0]).to(dev), torch.from_numpy(mid[1]).to(dev)
+    qd2 = torch.from_numpy(rng.random((3000, 64), dtype=np.float32)).to(dev)
+
+    def work(check):
+        for (q, r), want in zip((small, mid, big), wants):
+            got = pkg.search(q, r)
+            if check:
+                assert np.array_equal(got, want)
+        got = pkg.search_multi(mid[0], mid[1], num_devices=2, virtual=True)
+        if check:
+            assert np.array_equal(got, wants[1])
+        ix = pkg.Index(rd, profile=True)
+        a = ix.search(qd)
+        ix.search(qd2)                       # query workspace regrow while the first search may still run
+        ix.stats()
+        ix.near_ties()
+        ix.close()                           # destroy right behind asynchronous work
+        ix2 = pkg.Index(rd)                  # re-uses (or not) the blocks just handed back
+        b = ix2.search(qd)
+        ix2.close()
+        if check:
+            torch.cuda.current_stream().synchronize()
+            assert np.array_equal(a.cpu().numpy(), wants[1]) and np.array_equal(b.cpu().numpy(), wants[1])
+
+    work(True)                               # warm: code objects, pool, pinned scratch, library streams
+    side = torch.cuda.Stream()               # torch's side streams are hipStreamNonBlocking
+    done = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(int(12e9))         # a foreign kernel that spins for several seconds
+        done.record()
+    import time
+    t0 = time.perf_counter()
+    work(True)
+    dt = time.perf_counter() - t0
+    still_running = not done.query()
+    side.synchronize()
+    assert still_running, f"the library waited for the application's stream ({dt:.2f} s)"
+    assert dt < 3.0, dt
+
+
+def test_entry_points_restore_the_current_device(pkg, orc):
+    """Every C-ABI entry point that selects a device puts the caller's current device back (round 2 left the
+    index's device selected, and nns_search_*_multi ended with hipSetDevice(0)).  Needs two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (the driver's multi-GPU box)")
+    rng = np.random.default_rng(59)
+    q, r = rng.random((200, 32), dtype=np.float32), rng.random((5000, 32), dtype=np.float32)
+    want = orc.v0_search(q, r, threads=8)[0]
+    torch.cuda.set_device(1)
+    assert np.array_equal(pkg.search(q, r, device=0), want) and torch.cuda.current_device() == 1
+    assert np.array_equal(pkg.search_multi(q, r, num_devices=2, force_collective=True), want)
+    assert pkg.multi_last_exchange_ranks() == 2 and torch.cuda.current_device() == 1
+    rd = torch.from_numpy(r).to("cuda:0")
+    ix = pkg.Index(rd)
+    assert torch.cuda.current_device() == 1
+    got = ix.search(torch.from_numpy(q).to("cuda:0"), stream=torch.cuda.current_stream(0))
+    assert torch.cuda.current_device() == 1
+    ix.stats()
+    ix.close()
+    assert torch.cuda.current_device() == 1
+    torch.cuda.synchronize(0)
+    assert np.array_equal(got.cpu().numpy(), want)
+    torch.cuda.set_device(0)
