@@ -841,6 +841,323 @@ __global__ __launch_bounds__(256) void exact_lane_ref_tiled_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// K1c: the HBM-bound shapes — a handful of queries (m <= 4) against a long ref stream.
+// ---------------------------------------------------------------------------
+// The reference driver's m = 1 samples (main.cu:39-42) and SURVEY 8(f1)'s 1 x 1 M x 16: n * k * 4 bytes read once, a few
+// flops per byte — the stream from HBM is the whole cost (V7 splits such a search over G blocks and finishes on the
+// host: core.cu:655-696).  What K1b's lane-per-row form does wrong on short rows: with 64-byte rows a float4 load
+// per lane touches 64 different rows, i.e. an eighth of each 128-byte line per wave-instruction, four instructions
+// deep; and the search took three launches' worth of overheads (key fill, scan with one atomicMin per workgroup on
+// ONE address, nothing fused).  K1c instead:
+//   * every wave-instruction reads 1 KiB of CONTIGUOUS refs (lane i: 16 bytes at base + 16 i), U of them per tile and
+//     the next tile's U already in flight while the current one is consumed (2U = 8 loads of 16 B per lane);
+//   * a row of k = 4 L floats is then spread over L consecutive lanes (L = 1, 2, 4, 8).  V0's sum is a strict
+//     t-ascending chain, so partial sums per lane would change the rounding: instead the chain is PASSED ALONG the L
+//     lanes — L phases, in phase p every lane extends the sum it holds by its own four dimensions and hands the
+//     result to its right neighbour (DPP row_shr:1, no LDS).  The lane that owns quarter p has, in phase p, exactly
+//     V0's partial sum over dimensions 0 .. 4p - 1 (induction from the zero every lane starts with; what the other
+//     lanes compute in that phase is never used), so after phase L - 1 the row's last lane holds V0's distance bit for
+//     bit.  L-fold redundant VALU work — ~50 instructions per KiB at k = 16, a quarter of the HBM time per CU;
+//   * k = 1, 2, 3: a row per lane with ONE k-dword load (global_load_dwordx3 at k = 3: 768 contiguous bytes per
+//     wave-instruction);
+//   * ONE launch: lane -> wave (packed-key shuffles) -> workgroup (LDS) -> the grid through returning 64-bit
+//     atomic mins into EIGHT accumulator shards (workgroup b uses shard b & 7 — a sharding, not a placement
+//     assumption: 512 workgroups finishing together would otherwise queue ~11 ns each on one address) and a
+//     two-level arrival count (shard, then top); the last workgroup of all exchanges the shards back to
+//     NNS_KEY_NONE (read + re-arm in one RMW), writes the keys and, optionally, the unpacked index / distance.
+//     Every cross-workgroup access is an agent-scope atomic RMW, both sides: performed at the memory side, never
+//     served from an XCD's L2 or a CU's L1.
+struct StreamMerge {
+    nns_key *acc;    // [8 shards][4 queries], NNS_KEY_NONE between launches
+    int *cnt;        // [8] arrivals per shard + [8] = top-level arrivals; zero between launches
+    int *idx_out;    // optional fused unpack
+    float *dist_out;
+};
+constexpr int kStreamShards = 8, kStreamMaxQ = 4;
+constexpr size_t kStreamWsKeys = kStreamShards * kStreamMaxQ + 8;   // accumulators + 16 ints
+
+__device__ __forceinline__ float dpp_shr1(float v)
+{
+    // lane i <- lane i - 1 within its row of 16 lanes (row_shr:1); lanes without a source keep `v`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x111, 0xF, 0xF, false));
+}
+
+// the grid-level merge of K1c: `mine` = this workgroup's key of query qi (threads qi < mq of the workgroup call it)
+__device__ __forceinline__ void stream_merge(const StreamMerge &mg, nns_key *keys, int mq, nns_key mine, int *s_flag)
+{
+    const int tid = threadIdx.x;
+    const int shard = blockIdx.x & (kStreamShards - 1);
+    if (tid < mq) {
+        const nns_key old = __hip_atomic_fetch_min(&mg.acc[shard * kStreamMaxQ + tid], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(old));   // returning atomic: its value back = it has been performed at the memory side
+    }
+    __syncthreads();                   // every min of the workgroup is done before the arrival is counted
+    if (tid == 0) {
+        const int in_shard = ((int)gridDim.x - shard + kStreamShards - 1) / kStreamShards;   // workgroups with b & 7 == shard
+        int last = 0;
+        if (__hip_atomic_fetch_add(&mg.cnt[shard], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+            const int nshards = (int)gridDim.x < kStreamShards ? (int)gridDim.x : kStreamShards;   // shards that have workgroups
+            last = __hip_atomic_fetch_add(&mg.cnt[kStreamShards], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nshards - 1;
+        }
+        *s_flag = last;
+    }
+    __syncthreads();
+    if (!*s_flag) return;              // (workgroup-uniform)
+    if (tid < mq) {
+        nns_key v = NNS_KEY_NONE;
+        for (int s = 0; s < kStreamShards; ++s) {   // read + re-arm in ONE memory-side RMW per shard
+            const nns_key o = __hip_atomic_exchange(&mg.acc[s * kStreamMaxQ + tid], (nns_key)NNS_KEY_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = o < v ? o : v;
+        }
+        keys[tid] = v;
+        if (mg.idx_out) {
+            mg.idx_out[tid] = (int)(uint32_t)(v & 0xFFFFFFFFull);   // NNS_KEY_NONE -> 0, as V0
+            if (mg.dist_out) mg.dist_out[tid] = __uint_as_float((uint32_t)(v >> 32));
+        }
+    }
+    if (tid <= kStreamShards) __hip_atomic_store(&mg.cnt[tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+}
+
+// lanes -> wave -> workgroup for QT queries; returns (threads qi < QT) the workgroup's key of query qi
+template <int QT, int NW>
+__device__ __forceinline__ nns_key stream_block_key(const float (&best)[QT], const int (&bidx)[QT], int64_t index_base,
+                                                    nns_key (*wkeys)[QT])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        const nns_key key = wave_min_key(make_key(best[u], index_base + bidx[u]));
+        if (lane == 0) wkeys[wave][u] = key;
+    }
+    __syncthreads();
+    nns_key mine = NNS_KEY_NONE;
+    if (threadIdx.x < QT) {
+        const int nw = blockDim.x >> 6;
+        for (int w = 0; w < nw; ++w) mine = wkeys[w][threadIdx.x] < mine ? wkeys[w][threadIdx.x] : mine;
+    }
+    return mine;
+}
+
+// k = 4 L (L = 1, 2, 4, 8): L lanes per row, chain passed along them
+template <int L, int QT, int U, int NW>
+__global__ __launch_bounds__(64 * NW) void exact_stream_kernel(int n, int mq, const float *__restrict__ q,
+                                                              const float4 *__restrict__ r4, int64_t index_base,
+                                                              nns_key *__restrict__ keys, const StreamMerge mg)
+{
+    constexpr int K = 4 * L;
+    constexpr int LOGL = L == 1 ? 0 : (L == 2 ? 1 : (L == 4 ? 2 : 3));
+    constexpr int TILE = 64 * U;                                    // 16-byte pieces per wave and tile
+    __shared__ nns_key wkeys[NW][QT];
+    __shared__ int s_flag;
+    const int lane = threadIdx.x & 63;
+    const int part = lane & (L - 1);                                // which four dimensions of its row this lane holds
+    const bool lastpart = part == L - 1;
+    float qv[QT][4];
+#pragma unroll
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qv[u][e] = u < mq ? q[(size_t)u * K + 4 * part + e] : 0.0f;
+    float best[QT];
+    int bidx[QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        best[u] = __builtin_inff();
+        bidx[u] = 0;
+    }
+    const int64_t total = (int64_t)n * L;                           // 16-byte pieces in all
+    const int64_t full_tiles = total / TILE;
+    const int64_t nwaves = (int64_t)gridDim.x * NW;
+    int64_t t = (int64_t)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;   // waves of a workgroup: gridDim.x tiles apart
+
+    auto consume = [&](const float4 (&b)[U], int64_t tile) __attribute__((always_inline)) {
+        const int row0 = (int)((tile * TILE + lane) >> LOGL);       // (< n < 2^31)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = row0 + u * (64 >> LOGL);
+#pragma unroll
+            for (int qi = 0; qi < QT; ++qi) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int p = 0; p < L; ++p) {
+                    if (p) sum = dpp_shr1(sum);                     // the chain moves one lane to the right
+                    sum = v0_step(sum, qv[qi][0], b[u].x);
+                    sum = v0_step(sum, qv[qi][1], b[u].y);
+                    sum = v0_step(sum, qv[qi][2], b[u].z);
+                    sum = v0_step(sum, qv[qi][3], b[u].w);
+                }
+                const bool imp = lastpart && sum < best[qi];        // strict: the first (lowest) row of this lane wins; NaN / INF never
+                best[qi] = imp ? sum : best[qi];
+                bidx[qi] = imp ? row : bidx[qi];
+            }
+        }
+    };
+    {
+        float4 cur[U], nxt[U];
+        auto fetch = [&](float4 (&b)[U], int64_t tile) __attribute__((always_inline)) {
+            const float4 *p = r4 + tile * TILE + lane;
+#pragma unroll
+            for (int u = 0; u < U; ++u) b[u] = p[u * 64];
+        };
+        if (t < full_tiles) fetch(cur, t);
+        while (t < full_tiles) {
+            const int64_t tn = t + nwaves;
+            if (tn < full_tiles) fetch(nxt, tn);
+            consume(cur, t);
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+            t = tn;
+        }
+        // the ragged last tile: the wave whose turn it is, every piece guarded (a piece past the end counts as NaN)
+        if (t == full_tiles && total > full_tiles * TILE) {
+            const float nanv = __builtin_nanf("");
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t c = full_tiles * TILE + u * 64 + lane;
+                cur[u] = c < total ? r4[c] : make_float4(nanv, nanv, nanv, nanv);
+            }
+            consume(cur, full_tiles);
+        }
+    }
+    const nns_key mine = stream_block_key<QT, NW>(best, bidx, index_base, wkeys);
+    stream_merge(mg, keys, mq, mine, &s_flag);
+}
+
+// k = 1, 2, 3: a row per lane, one K-dword load each (contiguous across the wave)
+template <int K>
+struct __attribute__((packed, aligned(4))) RowK {
+    float v[K];
+};
+template <int K, int QT, int U, int NW>
+__global__ __launch_bounds__(64 * NW) void exact_stream_rows_kernel(int n, int mq, const float *__restrict__ q,
+                                                                   const float *__restrict__ r, int64_t index_base,
+                                                                   nns_key *__restrict__ keys, const StreamMerge mg)
+{
+    constexpr int TILE = 64 * U;                                    // rows per wave and tile
+    __shared__ nns_key wkeys[NW][QT];
+    __shared__ int s_flag;
+    const int lane = threadIdx.x & 63;
+    float qv[QT][K];
+#pragma unroll
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int e = 0; e < K; ++e) qv[u][e] = u < mq ? q[(size_t)u * K + e] : 0.0f;
+    float best[QT];
+    int bidx[QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        best[u] = __builtin_inff();
+        bidx[u] = 0;
+    }
+    const int64_t full_tiles = n / TILE;
+    const int64_t nwaves = (int64_t)gridDim.x * NW;
+    int64_t t = (int64_t)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+    const RowK<K> *rows = reinterpret_cast<const RowK<K> *>(r);
+
+    auto consume = [&](const RowK<K> (&b)[U], int64_t tile) __attribute__((always_inline)) {
+        const int row0 = (int)(tile * TILE) + lane;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int qi = 0; qi < QT; ++qi) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int e = 0; e < K; ++e) sum = v0_step(sum, qv[qi][e], b[u].v[e]);
+                const bool imp = sum < best[qi];
+                best[qi] = imp ? sum : best[qi];
+                bidx[qi] = imp ? row0 + u * 64 : bidx[qi];
+            }
+        }
+    };
+    {
+        RowK<K> cur[U], nxt[U];
+        auto fetch = [&](RowK<K> (&b)[U], int64_t tile) __attribute__((always_inline)) {
+            const RowK<K> *p = rows + tile * TILE + lane;
+#pragma unroll
+            for (int u = 0; u < U; ++u) b[u] = p[u * 64];
+        };
+        if (t < full_tiles) fetch(cur, t);
+        while (t < full_tiles) {
+            const int64_t tn = t + nwaves;
+            if (tn < full_tiles) fetch(nxt, tn);
+            consume(cur, t);
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+            t = tn;
+        }
+        if (t == full_tiles && n > full_tiles * TILE) {
+            RowK<K> nanrow;
+#pragma unroll
+            for (int e = 0; e < K; ++e) nanrow.v[e] = __builtin_nanf("");
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t c = full_tiles * TILE + u * 64 + lane;
+                cur[u] = c < n ? rows[c] : nanrow;
+            }
+            consume(cur, full_tiles);
+        }
+    }
+    const nns_key mine = stream_block_key<QT, NW>(best, bidx, index_base, wkeys);
+    stream_merge(mg, keys, mq, mine, &s_flag);
+}
+
+#ifndef NNS_K1C_U
+#define NNS_K1C_U 4
+#endif
+#ifndef NNS_K1C_NW
+#define NNS_K1C_NW 4
+#endif
+#ifndef NNS_K1C_WGS
+#define NNS_K1C_WGS 1024   // workgroups at most (4 per CU)
+#endif
+static bool k1c_shape(int k, int m, const float *r)
+{
+    if (m < 1 || m > kStreamMaxQ) return false;
+    if (k == 1 || k == 2 || k == 3) return true;
+    return (k == 4 || k == 8 || k == 16 || k == 32) && (((uintptr_t)r & 15) == 0);
+}
+
+template <int QT>
+static int launch_k1c_q(int k, int m, int n, const float *q, const float *r, int64_t base, nns_key *keys, const StreamMerge &mg,
+                        hipStream_t st)
+{
+    constexpr int U = NNS_K1C_U, NW = NNS_K1C_NW;
+    const int64_t pieces = k < 4 ? (int64_t)n : (int64_t)n * (k / 4);          // 16-byte pieces (k >= 4) or rows
+    int64_t wgs = divup64(divup64(pieces, 64 * U), NW);                         // one tile per wave at least
+    if (wgs > NNS_K1C_WGS) wgs = NNS_K1C_WGS;
+    if (wgs < 1) wgs = 1;
+    const dim3 grid((unsigned)wgs), block(64 * NW);
+    const float4 *r4 = reinterpret_cast<const float4 *>(r);
+    switch (k) {
+    case 1: hipLaunchKernelGGL((exact_stream_rows_kernel<1, QT, U, NW>), grid, block, 0, st, n, m, q, r, base, keys, mg); break;
+    case 2: hipLaunchKernelGGL((exact_stream_rows_kernel<2, QT, U, NW>), grid, block, 0, st, n, m, q, r, base, keys, mg); break;
+    case 3: hipLaunchKernelGGL((exact_stream_rows_kernel<3, QT, U, NW>), grid, block, 0, st, n, m, q, r, base, keys, mg); break;
+    case 4: hipLaunchKernelGGL((exact_stream_kernel<1, QT, U, NW>), grid, block, 0, st, n, m, q, r4, base, keys, mg); break;
+    case 8: hipLaunchKernelGGL((exact_stream_kernel<2, QT, U, NW>), grid, block, 0, st, n, m, q, r4, base, keys, mg); break;
+    case 16: hipLaunchKernelGGL((exact_stream_kernel<4, QT, U, NW>), grid, block, 0, st, n, m, q, r4, base, keys, mg); break;
+    default: hipLaunchKernelGGL((exact_stream_kernel<8, QT, U, NW>), grid, block, 0, st, n, m, q, r4, base, keys, mg); break;
+    }
+    NNS_HIP(hipGetLastError());
+    return NNS_OK;
+}
+
+static int launch_k1c(int k, int m, int n, const float *q, const float *r, int64_t base, nns_key *keys, nns_key *ws,
+                      bool ws_fresh, int *idx_out, float *dist_out, hipStream_t st)
+{
+    StreamMerge mg;
+    mg.acc = ws;
+    mg.cnt = reinterpret_cast<int *>(ws + kStreamShards * kStreamMaxQ);
+    mg.idx_out = idx_out;
+    mg.dist_out = dist_out;
+    if (ws_fresh) {   // accumulators and counters re-arm themselves; a fresh workspace is armed once
+        NNS_TRY(launch_keys_fill(mg.acc, kStreamShards * kStreamMaxQ, NNS_KEY_NONE, st));
+        NNS_HIP(hipMemsetAsync(mg.cnt, 0, 16 * sizeof(int), st));
+    }
+    if (m == 1) return launch_k1c_q<1>(k, m, n, q, r, base, keys, mg, st);
+    if (m == 2) return launch_k1c_q<2>(k, m, n, q, r, base, keys, mg, st);
+    return launch_k1c_q<4>(k, m, n, q, r, base, keys, mg, st);
+}
+
 template <int QT, typename T>
 static int launch_k1b_t(int k, int n, const T *q, const T *r, const int *qlist,
                         const int *qcount, int mq, int groups, int64_t base, nns_key *keys,
@@ -913,6 +1230,7 @@ static bool k1a_dim(int k) { return k == 1 || k == 2 || k == 3 || k == 4 || k ==
 
 size_t exact_workspace_keys(int k, int m, int n)
 {
+    if (m <= kStreamMaxQ && (k <= 4 || k == 8 || k == 16 || k == 32)) return kStreamWsKeys;   // K1c (if the refs are aligned)
     if (m < 64 || !k1a_dim(k)) return 0;
     switch (k) {
     case 1: return k1a_workspace_keys<1>(m, n);
@@ -940,6 +1258,9 @@ int launch_exact_search(int k, int m, int n, const float *q, const float *r,
         default: break;
         }
     }
+    // a handful of queries over short rows: the HBM-streaming form, one launch (needs its merge workspace)
+    if (k1c_shape(k, m, r) && ws && ws_keys >= kStreamWsKeys)
+        return launch_k1c(k, m, n, q, r, index_base, keys, ws, ws_fresh, idx_out, dist_out, st);
     NNS_TRY(check_k(k));
     NNS_TRY(launch_keys_fill(keys, m, NNS_KEY_NONE, st));
     const int qt = pick_qt(k, m);

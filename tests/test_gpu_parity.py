@@ -1622,3 +1622,58 @@ def test_entry_points_restore_the_current_device(pkg, orc):
     torch.cuda.synchronize(0)
     assert np.array_equal(got.cpu().numpy(), want)
     torch.cuda.set_device(0)
+
+
+def test_k1c_streaming_kernel_few_queries(pkg, orc):
+    """K1c (m <= 4 queries over short rows: the HBM-bound shapes of main.cu:39-42): rows spread over L lanes with V0's
+    chain passed along them (k = 4, 8, 16, 32), a row per lane with one k-dword load (k = 1, 2, 3); full and ragged
+    tiles, exact ties (lowest index), NaN / INF rows, index_base, the in-kernel sharded merge re-arming itself
+    call after call, the fused unpack, and an unaligned ref pointer falling back to K1b."""
+    rng = np.random.default_rng(60)
+    dev = torch.device("cuda:0")
+    for k in (1, 2, 3, 4, 8, 16, 32):
+        for n in (1, 63, 64, 257, 1000, 4097, 70001, 300000):
+            for m in (1, 2, 3, 4):
+                if n > 5000 and m in (2, 3) and k not in (3, 16):
+                    continue
+                q = rng.random((m, k), dtype=np.float32)
+                r = rng.random((n, k), dtype=np.float32)
+                if n >= 64:
+                    r[n - 1] = r[7]                       # exact tie across the stream: index 7 wins if it is the minimum
+                    q[0] = r[7]
+                    r[n // 2] = np.nan
+                    r[n // 3, 0] = np.inf
+                want_idx, want_dist = orc.v0_search(q, r, threads=8)
+                idx, dist = pkg.search(q, r, return_distances=True, path="exact")
+                assert np.array_equal(idx, want_idx), (k, n, m)
+                assert np.array_equal(_bits(dist), _bits(want_dist)), (k, n, m)
+    # device API: one index searched repeatedly (accumulators / counters re-arm), index_base, fused unpack
+    for k, n in ((16, 100000), (3, 65536), (8, 5000)):
+        r = rng.random((n, k), dtype=np.float32)
+        rd = torch.from_numpy(r).to(dev)
+        ix = pkg.Index(rd, index_base=1000, path="exact")
+        for rep in range(5):
+            m = 1 + rep % 4
+            q = rng.random((m, k), dtype=np.float32)
+            want_idx, want_dist = orc.v0_search(q, r, threads=8)
+            qd = torch.from_numpy(q).to(dev)
+            keys = torch.empty(m, dtype=torch.int64, device=dev)
+            dist = torch.empty(m, dtype=torch.float32, device=dev)
+            idx = ix.search_indices(qd, keys, None, dist)
+            torch.cuda.synchronize()
+            assert np.array_equal(idx.cpu().numpy(), want_idx + 1000), (k, n, rep)
+            assert np.array_equal(_bits(dist.cpu().numpy()), _bits(want_dist))
+            assert np.array_equal((keys.cpu().numpy() & 0xFFFFFFFF).astype(np.int64), want_idx + 1000)
+        ix.close()
+    # refs that start 4 bytes off a 16-byte boundary: not K1c's 16-byte pieces — K1b takes over, same answer
+    k, n = 16, 5000
+    flat = torch.from_numpy(rng.random(n * k + 1, dtype=np.float32)).to(dev)
+    r_off = flat[1:].view(n, k)
+    assert r_off.data_ptr() % 16 == 4
+    q = rng.random((1, k), dtype=np.float32)
+    want_idx, _ = orc.v0_search(q, r_off.cpu().numpy(), threads=8)
+    ix = pkg.Index(r_off, path="exact")
+    got = ix.search(torch.from_numpy(q).to(dev))
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want_idx)
+    ix.close()
