@@ -904,19 +904,29 @@ __device__ __forceinline__ void stream_merge(const StreamMerge &mg, nns_key *key
     }
     __syncthreads();
     if (!*s_flag) return;              // (workgroup-uniform)
-    if (tid < mq) {
+    // read + re-arm in ONE memory-side RMW per (shard, query): thread 4 s + qi of the first wave takes shard s of
+    // query qi, all 32 exchanges in flight together (one round trip, not eight), then a shuffle min over the shards
+    static_assert(kStreamShards * kStreamMaxQ == 32 && kStreamMaxQ == 4, "thread 4 s + qi of the first wave");
+    if (tid < 64) {
         nns_key v = NNS_KEY_NONE;
-        for (int s = 0; s < kStreamShards; ++s) {   // read + re-arm in ONE memory-side RMW per shard
-            const nns_key o = __hip_atomic_exchange(&mg.acc[s * kStreamMaxQ + tid], (nns_key)NNS_KEY_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < kStreamShards * kStreamMaxQ && (tid & (kStreamMaxQ - 1)) < mq)
+            v = __hip_atomic_exchange(&mg.acc[tid], (nns_key)NNS_KEY_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int off = kStreamMaxQ; off < kStreamShards * kStreamMaxQ; off <<= 1) {
+            const uint32_t lo = __shfl_xor((uint32_t)v, off, 64), hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
+            const nns_key o = ((nns_key)hi << 32) | lo;
             v = o < v ? o : v;
         }
-        keys[tid] = v;
-        if (mg.idx_out) {
-            mg.idx_out[tid] = (int)(uint32_t)(v & 0xFFFFFFFFull);   // NNS_KEY_NONE -> 0, as V0
-            if (mg.dist_out) mg.dist_out[tid] = __uint_as_float((uint32_t)(v >> 32));
+        if (tid < mq) {
+            keys[tid] = v;
+            if (mg.idx_out) {
+                mg.idx_out[tid] = (int)(uint32_t)(v & 0xFFFFFFFFull);   // NNS_KEY_NONE -> 0, as V0
+                if (mg.dist_out) mg.dist_out[tid] = __uint_as_float((uint32_t)(v >> 32));
+            }
         }
+        if (tid >= 32 && tid <= 32 + kStreamShards)   // re-arm the counters (other lanes of the same wave)
+            __hip_atomic_store(&mg.cnt[tid - 32], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid <= kStreamShards) __hip_atomic_store(&mg.cnt[tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
 }
 
 // lanes -> wave -> workgroup for QT queries; returns (threads qi < QT) the workgroup's key of query qi
@@ -1108,7 +1118,9 @@ __global__ __launch_bounds__(64 * NW) void exact_stream_rows_kernel(int n, int m
 #define NNS_K1C_NW 4
 #endif
 #ifndef NNS_K1C_WGS
-#define NNS_K1C_WGS 1024   // workgroups at most (4 per CU)
+#define NNS_K1C_WGS 512    // workgroups at most (2 per CU): few, long-lived waves — a wave's first-load latency and the
+                           // merge's atomic round trips are per workgroup (1 x 1 M x 16: 2048 workgroups 33.8 us, 1024
+                           // 24.9 us, 512 19.0 us on one device, HIP events)
 #endif
 static bool k1c_shape(int k, int m, const float *r)
 {

@@ -389,6 +389,8 @@ struct FilterArgs {
     int total_slots, slots_per_split, m_pad, kt;
     int bf16;               // tau mode: 0 fp32 operands, 1 bf16 points, 2 fp32 points rounded to bf16 operands
     int share_thr;          // short streams: a query's lanes adopt the smallest of their thresholds
+    int tile_rec;           // short streams: ONE record per (lane, ref tile) — (tile minimum, first ref of the lane's
+                            // rows) — instead of one per score within the threshold; K5 re-ranks the lane's rows
 #ifdef NNS_DIAG
     unsigned long long *stamps;   // diagnostic (NNS_FILTER_CLOCK): per-workgroup s_memtime / s_memrealtime
 #endif
@@ -645,10 +647,20 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
 #endif
         // (the tile minimum is recomputed here, on the cold path, rather than kept live across the branch)
-        tighten(st_c, tile_min(acc, st_c));
+        const float tmv = tile_min(acc, st_c);
+        tighten(st_c, tmv);
         // is any lane of the wave about to wrap its 64-entry ring (monotone inputs)?
         const bool roomy = __builtin_amdgcn_ballot_w64((cnt[st] & kCandCountMask) + 16 > kCandCap) == 0ull;
-        if constexpr (T16) {
+        if (a.tile_rec) {
+            // TILE RECORDS (short ref streams).  A wave carries 32 queries per state and a query improves on its
+            // t-th tile with probability ~1/t, so for the first ~32-64 tiles of a stream nearly EVERY tile takes
+            // this path in some lane, and a stream of 256 tiles (1024 queries x 1 M refs: 128 splits) takes it on
+            // a third of them — at the 16-deep tile, where a tile is 8 MFMAs, that was 40 % of the kernel.  Here
+            // the path is short whatever the scores look like: the lane records the TILE — its minimum and the first
+            // of the lane's 16 rows — and K5 evaluates V0's distance for those rows.  Completeness is unchanged:
+            // a ref within tau of the final minimum makes its tile's minimum <= every threshold the lane ever holds.
+            record(st_c, tmv, blk_global * 32 + 4 * h, roomy);
+        } else if constexpr (T16) {
             const f32x4 &lo = acc.template at<0, st>();
             const f32x4 &hi = acc.template at<1, st>();
             const int jbase = blk_global * 32 + 4 * (lane >> 4);
@@ -752,8 +764,12 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                         const f32x4 &o = acc.template at<ot, st>();
                         tighten(st_c, tmh[st]);
                         const bool roomy = __builtin_amdgcn_ballot_w64((cnt[st] & kCandCountMask) + 4 > kCandCap) == 0ull;
+                        if (a.tile_rec) {   // one record for the lane's four rows of this 16-ref tile (see record_all)
+                            record(st_c, tmh[st], jbase, roomy);
+                        } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) record(st_c, o[r], jbase + r, roomy);
+                            for (int r = 0; r < 4; ++r) record(st_c, o[r], jbase + r, roomy);
+                        }
                     }
                 });
             }
@@ -1092,6 +1108,10 @@ int launch_mfma_selftest(int kt, int bf16, const float *a, const float *b, const
 // ---- planning + launch ---------------------------------------------------------------
 // streams of at most this many 32-ref tiles per workgroup run with shared lane thresholds
 constexpr int64_t kShareThrMaxTiles = 2048;
+#ifndef NNS_F_TILEREC_MAX
+#define NNS_F_TILEREC_MAX 2048
+#endif
+constexpr int64_t kTileRecMaxTiles = NNS_F_TILEREC_MAX;
 
 int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
 {
@@ -1158,6 +1178,19 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
     g->slots_per_split = divup(divup(g->total_slots, splits), slots_per_block) * slots_per_block;   // whole blocks
     g->splits = divup(g->total_slots, g->slots_per_split);
     g->slot_pts = slot_pts;
+    // short streams (every tile of a stream of T tiles is slow until ~64 tiles in): share thresholds among a query's
+    // lanes, and record tiles instead of single scores; long streams (C3: 16384 tiles, C5: 8192) keep private
+    // thresholds and per-score records.  Tile records need K5's one-wave-per-query form (splits >= 4: a tile's rows
+    // are evaluated by 16 lanes side by side).
+    const int64_t stream_tiles = (int64_t)g->slots_per_split * (slot_pts / 32 > 0 ? slot_pts / 32 : 1) / (slots_per_block > 1 ? slots_per_block : 1);
+    g->share_thr = stream_tiles <= kShareThrMaxTiles ? 1 : 0;
+    g->tile_rec = (stream_tiles <= kTileRecMaxTiles && g->splits >= 4) ? 1 : 0;
+#ifdef NNS_F_NOSHARE   // (A/B builds)
+    g->share_thr = 0;
+#endif
+#ifdef NNS_F_NOTILEREC
+    g->tile_rec = 0;
+#endif
     return NNS_OK;
 }
 
@@ -1197,12 +1230,8 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
     a.m_pad = g.m_pad;
     a.kt = g.kt;
     a.bf16 = g.mixed ? 2 : g.bf16;
-    // short streams (every tile of a stream of T tiles is slow until ~128 tiles in): share thresholds
-    // among a query's lanes; long streams (C3: 16384 tiles, C5: 8192) keep them private
-    a.share_thr = (int64_t)g.slots_per_split * (g.n_pad / g.total_slots / 32) <= kShareThrMaxTiles ? 1 : 0;
-#ifdef NNS_F_NOSHARE   // (A/B builds)
-    a.share_thr = 0;
-#endif
+    a.share_thr = g.share_thr;   // (filter_plan)
+    a.tile_rec = g.tile_rec;
 #ifdef NNS_DIAG
     a.stamps = nullptr;
     const char *clk = getenv("NNS_FILTER_CLOCK");

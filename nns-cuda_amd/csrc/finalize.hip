@@ -159,9 +159,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(
 // 2 * splits candidate lists, and walking them from one thread serialises hundreds of
 // dependent loads.  Lanes take lists l, l + 64, ...; the minimum score and the final key
 // are reduced across the wave with packed-key / float shuffles.
+//
+// TILE RECORDS (FilterGeom.tile_rec, short ref streams): an entry is (minimum of the lane's scores of one ref tile,
+// first ref of the lane's rows of that tile) — 16 rows j + 8 g + e (g, e < 4) of a 32 x 32 MFMA tile, 4 rows j + e of a
+// 16 x 16 one.  The minimum over the entries is still the filter's minimum a of the query, and every ref with a score
+// <= a + tau(a) sits in a tile whose minimum is <= a + tau(a): the members of C_i are among the rows of the entries
+// within the threshold.  Each such entry is evaluated by 16 (4) lanes side by side, one row each, with V0's
+// arithmetic; rows that are not in C_i take part in the exact minimum too, which cannot change V0's answer.
 template <typename T>
 __global__ __launch_bounds__(256) void finalize_wave_kernel(
-    int kt, int bf16, int lpq, int m_pad, int splits, int k, int m, int n, const T *__restrict__ q,
+    int kt, int bf16, int lpq, int tile_rec, int m_pad, int splits, int k, int m, int n, const T *__restrict__ q,
     const T *__restrict__ r, const CandEntry *__restrict__ lists, const int *__restrict__ counts,
     const float *__restrict__ qnorm, DevScalars *__restrict__ scal, int64_t index_base,
     nns_key *__restrict__ keys, int *__restrict__ amb_list, int *__restrict__ multi_list)
@@ -198,6 +205,50 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
         const float thr = a + tau_of(tc, a);
         const T *qi = q + (size_t)i * k;
         const bool vec = (k & 3) == 0 && (((uintptr_t)q | (uintptr_t)r) & (4 * sizeof(T) - 1)) == 0;
+        if (tile_rec) {
+            // the lanes walk their lists in lockstep; an entry within the threshold is broadcast and its rows are
+            // evaluated side by side, one lane per row (a V0 chain is sequential in t: the parallelism is over rows)
+            const int nr = lpq == 4 ? 4 : 16;
+            const int joff = lpq == 4 ? lane : (lane & 3) + 8 * (lane >> 2);
+            for (int l0 = 0; l0 < nlists; l0 += 64) {
+                const int l = l0 + lane;
+                int c = 0;
+                const CandEntry *lp = lists;
+                if (l < nlists) {
+                    const int s = l >> lsh, h = l & (lpq - 1);
+                    const size_t lblk = (size_t)s * (m_pad >> ush) + (i >> ush);
+                    const int ln = (h << ush) + (i & qmask);
+                    const int cw = counts[lblk * 64 + ln] & kCandCountMask;
+                    c = cw < kCandCap ? cw : kCandCap;
+                    lp = lists + lblk * (kCandCap * 64) + ln;
+                }
+                int cmax = c;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const int o = __shfl_xor(cmax, off, 64);
+                    cmax = o > cmax ? o : cmax;
+                }
+                for (int e = 0; e < cmax; ++e) {
+                    CandEntry ce;
+                    ce.s = __builtin_inff();
+                    ce.j = 0;
+                    if (e < c) ce = lp[e * 64];
+                    const bool hit = e < c && ce.s <= thr;
+                    if (hit) ++ncand;   // (entries, i.e. tiles, within the threshold)
+                    unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                    while (mask) {      // (wave-uniform)
+                        const int src = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        const int j = __shfl(ce.j, src, 64) + joff;
+                        if (lane < nr && j < n) {
+                            const float sum = v0_distance(qi, r + (size_t)j * k, k, vec);
+                            const nns_key key = make_key(sum, index_base + j);
+                            best = key < best ? key : best;
+                        }
+                    }
+                }
+            }
+        } else
         for (int l = lane; l < nlists; l += 64) {
             const int s = l >> lsh, h = l & (lpq - 1);
             const size_t lblk = (size_t)s * (m_pad >> ush) + (i >> ush);
@@ -246,14 +297,18 @@ int launch_finalize(const FilterGeom &g, int k, int m, int n, const void *q, con
     if (g.splits >= 4) {   // few queries, many lists per query: one wave per query
         if (data_bf16)
             hipLaunchKernelGGL(finalize_wave_kernel<uint16_t>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, mode,
-                               g.lpq, g.m_pad, g.splits, k, m, n, (const uint16_t *)q, (const uint16_t *)r, lists,
+                               g.lpq, g.tile_rec, g.m_pad, g.splits, k, m, n, (const uint16_t *)q, (const uint16_t *)r, lists,
                                counts, qnorm, scal, index_base, keys, amb_list, multi_list);
         else
-            hipLaunchKernelGGL(finalize_wave_kernel<float>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, mode, g.lpq, g.m_pad,
-                               g.splits, k, m, n, (const float *)q, (const float *)r, lists, counts, qnorm, scal,
+            hipLaunchKernelGGL(finalize_wave_kernel<float>, dim3(divup(m, 4)), dim3(256), 0, st, g.kt, mode, g.lpq, g.tile_rec,
+                               g.m_pad, g.splits, k, m, n, (const float *)q, (const float *)r, lists, counts, qnorm, scal,
                                index_base, keys, amb_list, multi_list);
         NNS_HIP(hipGetLastError());
         return NNS_OK;
+    }
+    if (g.tile_rec) {   // (filter_plan couples tile records to splits >= 4)
+        set_error("internal: tile records need the one-wave-per-query finalize");
+        return NNS_ERR_INVALID;
     }
     if (data_bf16)
         hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(divup(g.m_pad / (64 / g.lpq), 4)), dim3(256), 0, st, g.kt, mode, g.lpq, g.m_pad,

@@ -154,6 +154,9 @@ struct FilterGeom {
     int slots_per_split;
     int qgroups;          // grid.x
     int slot_pts;         // refs per ring slot
+    int share_thr;        // short ref streams: a query's lanes share their record thresholds
+    int tile_rec;         // short ref streams: candidate entries are (tile minimum, first ref of the lane's rows of that
+                          // tile) — K5 evaluates all of the lane's rows — instead of (score, ref)
 };
 
 // One candidate of the filter: score s = |y'|^2 - 2 x'.y' and shard-local ref index.

@@ -1562,41 +1562,52 @@ def test_library_never_waits_for_foreign_streams(pkg, orc):
     qd, rd = torch.from_numpy(mid[0]).to(dev), torch.from_numpy(mid[1]).to(dev)
     qd2 = torch.from_numpy(rng.random((3000, 64), dtype=np.float32)).to(dev)
 
-    def work(check):
-        for (q, r), want in zip((small, mid, big), wants):
-            got = pkg.search(q, r)
-            if check:
-                assert np.array_equal(got, want)
-        got = pkg.search_multi(mid[0], mid[1], num_devices=2, virtual=True)
-        if check:
-            assert np.array_equal(got, wants[1])
+    marks = []
+
+    def mark(name):
+        marks.append((name, __import__("time").perf_counter()))
+
+    def work():
+        mark("begin")
+        for name, (q, r), want in zip(("small", "mid", "big"), (small, mid, big), wants):
+            assert np.array_equal(pkg.search(q, r), want)
+            mark("whole call " + name)
+        assert np.array_equal(pkg.search_multi(mid[0], mid[1], num_devices=2, virtual=True), wants[1])
+        mark("search_multi (virtual shards)")
         ix = pkg.Index(rd, profile=True)
+        mark("index create")
         a = ix.search(qd)
+        mark("search")
         ix.search(qd2)                       # query workspace regrow while the first search may still run
+        mark("search, workspace regrow")
         ix.stats()
+        mark("stats")
         ix.near_ties()
+        mark("near_ties")
         ix.close()                           # destroy right behind asynchronous work
+        mark("destroy")
         ix2 = pkg.Index(rd)                  # re-uses (or not) the blocks just handed back
         b = ix2.search(qd)
         ix2.close()
-        if check:
-            torch.cuda.current_stream().synchronize()
-            assert np.array_equal(a.cpu().numpy(), wants[1]) and np.array_equal(b.cpu().numpy(), wants[1])
+        mark("create + search + destroy")
+        torch.cuda.current_stream().synchronize()
+        assert np.array_equal(a.cpu().numpy(), wants[1]) and np.array_equal(b.cpu().numpy(), wants[1])
+        mark("results to the host")
 
-    work(True)                               # warm: code objects, pool, pinned scratch, library streams
+    work()                                   # warm: code objects, pool, pinned scratch, library streams
+    torch.cuda.synchronize()
     side = torch.cuda.Stream()               # torch's side streams are hipStreamNonBlocking
     done = torch.cuda.Event()
     with torch.cuda.stream(side):
-        torch.cuda._sleep(int(12e9))         # a foreign kernel that spins for several seconds
+        torch.cuda._sleep(int(12e9))         # a foreign kernel that spins for ~5 s
         done.record()
-    import time
-    t0 = time.perf_counter()
-    work(True)
-    dt = time.perf_counter() - t0
+    marks.clear()
+    work()
     still_running = not done.query()
     side.synchronize()
-    assert still_running, f"the library waited for the application's stream ({dt:.2f} s)"
-    assert dt < 3.0, dt
+    spans = [(n1, round(1e3 * (t1 - t0), 2)) for (n0, t0), (n1, t1) in zip(marks, marks[1:])]
+    assert still_running, f"the library waited for the application's stream; ms per operation: {spans}"
+    assert marks[-1][1] - marks[0][1] < 3.0, spans
 
 
 def test_entry_points_restore_the_current_device(pkg, orc):
