@@ -97,6 +97,9 @@ enum {
                           * array: the layout v4::mat_inv_kernel produces, core.cu:293-306, :327) instead
                           * of r[j * k + t]; queries stay [m][k].  The library transposes once on the
                           * device into a copy it owns. */
+    NNS_RECORDS_PER_REF = 512, /* MFMA filter: keep the candidate records per SCORE (the form long reference streams
+                          * use) also on short streams, where AUTO records per (lane, ref tile) and lets K5 evaluate the
+                          * tile's rows — same results either way; lets tests and A/B runs drive both forms at any size */
     NNS_MULTI_FORCE_COLLECTIVE = 256 /* nns_search_*_multi, for tests: no single-GPU shortcut — even ONE shard runs the
                           * thread-per-GPU body, ncclCommInitAll and the grouped ncclAllReduce (core.cu:965-1057's
                           * shape), so that branch can be executed on a one-GPU box (a 1-rank all-reduce) */
@@ -257,7 +260,8 @@ int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const fl
 /* Diagnostic (host only, no device needed): the launch geometry the MFMA filter would use for a k-D search of
  * m queries over n refs.  out[0..11] = {tile depth kt, bf16 operands, fp32 points rounded to bf16 operands,
  * candidate lists per query, m_pad, n_pad, ring slots in total, ref-range splits (grid.y), slots per split,
- * query groups (grid.x), refs per ring slot, queries per workgroup}.  NNS_ERR_UNSUPPORTED beyond the deepest
+ * query groups (grid.x), refs per ring slot, queries per workgroup}; with out_len >= 14 also {lanes of a query
+ * share thresholds, records per ref tile} (the short-stream forms).  NNS_ERR_UNSUPPORTED beyond the deepest
  * tile.  Lets CPU tests check the planner's invariants (coverage, padding, whole blocks per split). */
 int nns_plan_filter(int k, int m, int n, int bf16_points, unsigned flags, int *out, int out_len);
 /* Diagnostic: what the filter's slow path does when the lanes that carry one query share their record

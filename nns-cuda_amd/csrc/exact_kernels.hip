@@ -1115,12 +1115,12 @@ __global__ __launch_bounds__(64 * NW) void exact_stream_rows_kernel(int n, int m
 #define NNS_K1C_U 4
 #endif
 #ifndef NNS_K1C_NW
-#define NNS_K1C_NW 4
+#define NNS_K1C_NW 8
 #endif
 #ifndef NNS_K1C_WGS
-#define NNS_K1C_WGS 512    // workgroups at most (2 per CU): few, long-lived waves — a wave's first-load latency and the
-                           // merge's atomic round trips are per workgroup (1 x 1 M x 16: 2048 workgroups 33.8 us, 1024
-                           // 24.9 us, 512 19.0 us on one device, HIP events)
+#define NNS_K1C_WGS 256    // workgroups at most (one of 8 waves per CU): few, long-lived waves — a wave's first-load
+                           // latency and the merge's atomic round trips are per workgroup (1 x 1 M x 16, HIP events on
+                           // one device: 2048 workgroups of 4 waves 33.8 us, 1024 24.9, 512 19.0; 256 of 8 waves 16.8)
 #endif
 static bool k1c_shape(int k, int m, const float *r)
 {

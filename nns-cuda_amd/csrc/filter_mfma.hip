@@ -166,6 +166,10 @@ struct AccSet16W {
 constexpr int kAblate = NNS_FILTER_ABLATE;
 
 constexpr int F_D = 4;                   // ring depth
+#ifndef NNS_F_DMA_AHEAD
+#define NNS_F_DMA_AHEAD 3
+#endif
+constexpr int F_DMA_AHEAD_MAX = NNS_F_DMA_AHEAD;   // (A/B builds: 2 = round 2's schedule for every operator)
 constexpr int F_SLOT_COORD = 32768;      // image bytes of one ring slot (32 fragment steps x 1 KiB)
 constexpr int F_SLOT_NORM = 2048;        // room for the slot's norms (up to 512 floats: the 16-deep tile)
 constexpr int F_SLOT_BYTES = F_SLOT_COORD + F_SLOT_NORM;
@@ -412,6 +416,15 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                   "norm pieces: one dword per lane, or dwordx4 pieces of 256 norms");
     constexpr int F_NP = SLOT_REFS <= 256 ? 1 : SLOT_REFS / 256;   // norm DMA pieces per slot
     static_assert(SLOT_REFS * 4 <= F_SLOT_NORM, "norm room of a ring slot");
+    // How far ahead of its interval a slot's DMA is issued.  Lagging SIMD partners still read slot s - 1 during
+    // the first half of interval s, so with four ring slots they can fill slot s + 2 at most: ONE interval between
+    // issue and deadline — plenty when an interval is 16 000 cycles (fp32 tiles), not when it is 1 000 - 4 000
+    // (bf16 tiles: a 1 KiB piece takes ~2 600 cycles from issue to landed under load, and round 2's waves sat in
+    // vmcnt(0) for half their cycles at the deep tiles).  Lock-step operators are done with slot s - 1 at the
+    // barrier that opens interval s, so they fill slot s + 3 = s - 1 (mod 4) and wait with a COUNTED vmcnt that
+    // leaves the youngest slot's pieces in flight across the barrier: TWO intervals of latency cover.
+    constexpr int AHEAD = (OP::kLag || F_DMA_AHEAD_MAX < 3) ? 2 : 3;
+    constexpr int F_PPS = F_PPW + F_NP;                 // DMA pieces per wave and slot
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -884,10 +897,10 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
 #endif
                 static_assert(d0 + sp * (F_PPW + F_NP) <= 32, "DMA pieces must fit the interval");
 #ifdef NNS_F_DMA_BURST
-                if constexpr (t == d0) issue(s + 2);
+                if constexpr (t == d0) issue(s + AHEAD);
 #else
                 if constexpr (t >= d0 && t < d0 + sp * (F_PPW + F_NP) && (t - d0) % sp == 0)
-                    issue_piece(s + 2, (t - d0) / sp);
+                    issue_piece(s + AHEAD, (t - d0) / sp);
 #endif
             }
             if constexpr (T16) {
@@ -927,10 +940,11 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     auto ring = [&](int s) __attribute__((always_inline)) { return smem + ((s + F_D) & (F_D - 1)) * F_SLOT_BYTES; };
     static_assert((F_D & (F_D - 1)) == 0, "ring depth must be a power of two");
 
-    // prologue: slots 0 and 1 in flight; confirm slot 0; start interval 0's first fragments
+    // prologue: slots 0 .. AHEAD - 1 in flight; confirm slot 0; start interval 0's first fragments
     issue(0);
     issue(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(F_PPW + F_NP) : "memory");
+    if constexpr (AHEAD == 3) issue(2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * F_PPS) : "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (T16) seed16(ring(0), 0, I0c{});   // the first block's tile-0 norms
     // (LAG 1 reads ring slot -1 here: garbage in, discarded — see the interval)
@@ -950,8 +964,10 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     auto slot_loop = [&](auto lag_c, auto dph_c) __attribute__((always_inline)) {
         auto sync_slot = [&]() __attribute__((always_inline)) {
             if constexpr ((kAblate & 1) == 0) {
-                // my share of slot s+1 has landed (issued an interval ago; the only DMA in flight)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // my share of slot s+1 has landed.  AHEAD 2: issued an interval ago, the only DMA in flight.  AHEAD 3:
+                // issued two intervals ago; the F_PPS pieces of slot s+2 issued since stay in flight (vmcnt counts
+                // in issue order; a candidate store of the slow path issued in between only makes the wait longer)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 2) * F_PPS) : "memory");
                 // everyone's share of slot s+1 has landed; everyone is done with slot s-2
                 __builtin_amdgcn_s_barrier();
             }
@@ -1113,7 +1129,7 @@ constexpr int64_t kShareThrMaxTiles = 2048;
 #endif
 constexpr int64_t kTileRecMaxTiles = NNS_F_TILEREC_MAX;
 
-int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
+int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed, bool per_ref)
 {
     if (mixed) bf16 = true;   // fp32 points, bf16 operands: the bf16 filter's geometry
     int kt = 0;
@@ -1184,7 +1200,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed)
     // are evaluated by 16 lanes side by side).
     const int64_t stream_tiles = (int64_t)g->slots_per_split * (slot_pts / 32 > 0 ? slot_pts / 32 : 1) / (slots_per_block > 1 ? slots_per_block : 1);
     g->share_thr = stream_tiles <= kShareThrMaxTiles ? 1 : 0;
-    g->tile_rec = (stream_tiles <= kTileRecMaxTiles && g->splits >= 4) ? 1 : 0;
+    g->tile_rec = (stream_tiles <= kTileRecMaxTiles && g->splits >= 4 && !per_ref) ? 1 : 0;
 #ifdef NNS_F_NOSHARE   // (A/B builds)
     g->share_thr = 0;
 #endif

@@ -33,10 +33,10 @@ using namespace nns;
 
 // one point of a tile image
 static size_t img_row_bytes(const FilterGeom &g) { return (size_t)g.kt * (g.bf16 ? 2 : 4); }
-// The filter's ring DMA runs two slots (32 KiB of image, slot_pts norms each) past the last one without a
+// The filter's ring DMA runs up to three slots (32 KiB of image, slot_pts norms each) past the last one without a
 // bounds branch: images and norm arrays carry that much padding (+ the over-read of a 128-norm piece)
-static size_t img_bytes(const FilterGeom &g, int pts_pad) { return (size_t)pts_pad * img_row_bytes(g) + 2 * 32768 + 4096; }
-static size_t norm_bytes(const FilterGeom &g, int pts_pad) { return ((size_t)pts_pad + 2 * g.slot_pts + 256) * sizeof(float); }
+static size_t img_bytes(const FilterGeom &g, int pts_pad) { return (size_t)pts_pad * img_row_bytes(g) + 3 * 32768 + 4096; }
+static size_t norm_bytes(const FilterGeom &g, int pts_pad) { return ((size_t)pts_pad + 3 * g.slot_pts + 256) * sizeof(float); }
 // below this many queries the AUTO path skips the MFMA filter (and, in the whole-call
 // entry points, its ref pre-pass too)
 static const int kTinyM = 64;
@@ -296,7 +296,7 @@ static int index_create_impl(nns_index **out, int device, int k, int n, const vo
             ix->ev_valid = true;
         }
         if (path == NNS_PATH_MFMA) {
-            if ((rc = filter_plan(k, 1, n, bf16 != 0, &ix->geom, ix->mixed)) != NNS_OK) break;
+            if ((rc = filter_plan(k, 1, n, bf16 != 0, &ix->geom, ix->mixed, (flags & NNS_RECORDS_PER_REF) != 0)) != NNS_OK) break;
             const FilterGeom &g = ix->geom;
             size_t ws = 0;
             prep_workspace_bytes(g.kt, &ws);
@@ -379,7 +379,7 @@ static int ensure_query_ws(nns_index *ix, int m, hipStream_t st)
 {
     FilterGeom g = ix->geom;
     FilterGeom gq{};
-    NNS_TRY(filter_plan(ix->k, m, ix->n, ix->bf16 != 0, &gq, ix->mixed));
+    NNS_TRY(filter_plan(ix->k, m, ix->n, ix->bf16 != 0, &gq, ix->mixed, (ix->flags & NNS_RECORDS_PER_REF) != 0));
     ix->geom = gq;   // same kt / n_pad / total_slots; m-dependent grid now filled in
     (void)g;
     if (gq.m_pad > ix->m_cap) {
@@ -734,10 +734,10 @@ int nns_plan_filter(int k, int m, int n, int bf16_points, unsigned flags, int *o
     if (!out || out_len < 12 || k <= 0 || m <= 0 || n <= 0) return NNS_ERR_INVALID;
     const bool mixed = !bf16_points && ((flags & NNS_FILTER_BF16) || (k > 256 && (flags & NNS_PATH_MASK) == NNS_PATH_AUTO));
     FilterGeom g{};
-    NNS_TRY(filter_plan(k, m, n, bf16_points != 0, &g, mixed));
-    const int v[12] = {g.kt, g.bf16, g.mixed, g.lpq, g.m_pad, g.n_pad, g.total_slots, g.splits, g.slots_per_split,
-                       g.qgroups, g.slot_pts, g.m_pad / g.qgroups};
-    memcpy(out, v, sizeof(v));
+    NNS_TRY(filter_plan(k, m, n, bf16_points != 0, &g, mixed, (flags & NNS_RECORDS_PER_REF) != 0));
+    const int v[14] = {g.kt, g.bf16, g.mixed, g.lpq, g.m_pad, g.n_pad, g.total_slots, g.splits, g.slots_per_split,
+                       g.qgroups, g.slot_pts, g.m_pad / g.qgroups, g.share_thr, g.tile_rec};
+    memcpy(out, v, (out_len >= 14 ? 14 : 12) * sizeof(int));
     return NNS_OK;
 }
 

@@ -291,7 +291,7 @@ int launch_prep_image_bf16(int order, int kt, int k, int npts, int npts_pad, con
                            unsigned *maxabs_bits, hipStream_t st);
 
 // filter_mfma.hip (K3 fp32 / K4 bf16)
-int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed = false);
+int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed = false, bool per_ref = false);
 int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const float *rnorm,
                   const float *qnorm, const DevScalars *scal, CandEntry *lists, int *counts,
                   hipStream_t st);

@@ -31,7 +31,10 @@ NNS_FILTER_BF16 = 128
 NNS_MULTI_FORCE_COLLECTIVE = 256
 NNS_KEY_NONE = 0x7F80000000000000
 
-_PATHS = {"auto": NNS_PATH_AUTO, "exact": NNS_PATH_EXACT, "mfma": NNS_PATH_MFMA}
+NNS_RECORDS_PER_REF = 512
+# "mfma_perref": the MFMA filter with per-score candidate records forced (the long-stream form) at any size
+_PATHS = {"auto": NNS_PATH_AUTO, "exact": NNS_PATH_EXACT, "mfma": NNS_PATH_MFMA,
+          "mfma_perref": NNS_PATH_MFMA | NNS_RECORDS_PER_REF}
 
 # every symbol include/nns.h declares (tests check the library exports them all)
 ABI_SYMBOLS = (
@@ -152,10 +155,10 @@ def selftest_mfma(a: np.ndarray, b: np.ndarray, c0: np.ndarray, bf16: bool = Fal
 
 def plan_filter(k: int, m: int, n: int, bf16: bool = False, flags: int = 0) -> dict:
     """nns_plan_filter: the MFMA filter's launch geometry for a shape (host only)."""
-    out = np.zeros(12, np.int32)
-    _check(lib.nns_plan_filter(k, m, n, int(bf16), flags, out.ctypes.data, 12), "nns_plan_filter")
+    out = np.zeros(14, np.int32)
+    _check(lib.nns_plan_filter(k, m, n, int(bf16), flags, out.ctypes.data, 14), "nns_plan_filter")
     names = ("kt", "bf16", "mixed", "lpq", "m_pad", "n_pad", "total_slots", "splits", "slots_per_split", "qgroups",
-             "slot_pts", "queries_per_wg")
+             "slot_pts", "queries_per_wg", "share_thr", "tile_rec")
     return dict(zip(names, (int(v) for v in out)))
 
 

@@ -21,8 +21,12 @@ def _check(pkg, orc, q, r, paths=("auto",), shards=(1,), want=None):
         want_idx, want_dist = orc.v0_search(q, r, threads=8)
     if want is not None:
         assert np.array_equal(want_idx, want), "oracle disagrees with the golden vector"
+    # the MFMA filter has two candidate-record forms — per (lane, ref tile) on short ref streams, per score on long
+    # ones; "mfma" drives whatever the planner picks for the size (small tests: tiles), "mfma_perref" forces the other
+    if "mfma" in paths and "mfma_perref" not in paths:
+        paths = tuple(paths) + ("mfma_perref",)
     for path in paths:
-        if path == "mfma" and q.shape[1] > 256:
+        if path.startswith("mfma") and q.shape[1] > 256:
             continue
         for s in shards:
             idx, dist = pkg.search(q, r, return_distances=True, shards=s, path=path)
@@ -208,11 +212,12 @@ def test_filter_sorted_refs_ring_lists(pkg, orc):
     r = (base + steps * direction).astype(np.float32)
     q = (base + rng.normal(0, 1e-3, (40, k))).astype(np.float32)
     _check(pkg, orc, q, r, paths=("mfma",), shards=(1, 3))
-    ix = pkg.Index(torch.from_numpy(r).cuda(), path="mfma")
-    ix.search(torch.from_numpy(q).cuda())
-    st = ix.stats()
-    assert st["path"] == 2 and st["ambiguous"] < q.shape[0], st
-    ix.close()
+    for path in ("mfma", "mfma_perref"):
+        ix = pkg.Index(torch.from_numpy(r).cuda(), path=path)
+        ix.search(torch.from_numpy(q).cuda())
+        st = ix.stats()
+        assert st["path"] == 2 and st["ambiguous"] < q.shape[0], (path, st)
+        ix.close()
 
 
 def test_filter_true_list_overflow_falls_back(pkg, orc):
@@ -225,11 +230,26 @@ def test_filter_true_list_overflow_falls_back(pkg, orc):
     r = np.concatenate([base[:700], np.repeat(hot, 80000, axis=0), base[700:]])
     q = np.concatenate([hot + rng.normal(0, 1e-4, (24, k)).astype(np.float32), rng.random((40, k), dtype=np.float32)])
     _check(pkg, orc, q, r, paths=("mfma",), shards=(1, 2))
-    ix = pkg.Index(torch.from_numpy(r).cuda(), path="mfma")
+    ix = pkg.Index(torch.from_numpy(r).cuda(), path="mfma_perref")    # a record per score: 80000 live candidates
     idx = ix.search(torch.from_numpy(q).cuda())
     st = ix.stats()
     assert st["ambiguous"] >= 24, st
     assert (idx[:24].cpu().numpy() == 700).all()
+    ix.close()
+    # a record per (lane, ref tile) — what a stream this short uses by itself — overflows only when more than 64
+    # TILES of one stream hold live candidates: 600000 duplicates over 256 streams
+    k = 32
+    base = rng.random((2000, k), dtype=np.float32)
+    hot = rng.random((1, k), dtype=np.float32)
+    r = np.concatenate([base[:700], np.repeat(hot, 600000, axis=0), base[700:]])
+    q = np.concatenate([hot + rng.normal(0, 1e-4, (24, k)).astype(np.float32), rng.random((40, k), dtype=np.float32)])
+    assert pkg.plan_filter(k, q.shape[0], r.shape[0])["tile_rec"] == 1
+    ix = pkg.Index(torch.from_numpy(r).cuda(), path="mfma")
+    idx = ix.search(torch.from_numpy(q).cuda())
+    st = ix.stats()
+    want_idx, _ = orc.v0_search(q, r, threads=8)
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+    assert st["ambiguous"] >= 24 and (want_idx[:24] == 700).all(), st
     ix.close()
 
 
@@ -382,8 +402,10 @@ def _check_bf16(pkg, orc, q, r, paths=("auto",), shards=(1,)):
     assert np.array_equal((qw.view(np.uint32) >> 16).astype(np.uint16), qb)   # same rounding as the oracle
     with np.errstate(all="ignore"):
         want_idx, want_dist = orc.v0_search(qw, rw, threads=8)
+    if "mfma" in paths and "mfma_perref" not in paths:   # both candidate-record forms (see _check)
+        paths = tuple(paths) + ("mfma_perref",)
     for path in paths:
-        if path == "mfma" and q.shape[1] > 1024:
+        if path.startswith("mfma") and q.shape[1] > 1024:
             continue
         for s in shards:
             idx, dist = pkg.search_bf16(qb, rb, return_distances=True, shards=s, path=path)

@@ -14,6 +14,12 @@ def _check_plan(p, k, m, n):
     assert p["splits"] >= 1 and p["slots_per_split"] >= 1
     assert p["splits"] * p["slots_per_split"] >= p["total_slots"] > (p["splits"] - 1) * p["slots_per_split"]
     assert p["splits"] <= 65535
+    # record form: per (lane, ref tile) only on short streams, and only with K5's one-wave-per-query form
+    tiles_per_stream = p["slots_per_split"] * max(p["slot_pts"], 32) // 32 // (2 if p["kt"] == 1024 else 1)
+    if p["tile_rec"]:
+        assert p["splits"] >= 4 and tiles_per_stream <= 2048 and p["share_thr"] == 1
+    elif p["splits"] >= 4:
+        assert tiles_per_stream > 2048
     # candidate list memory stays bounded (512 B per lane-list)
     assert p["splits"] * p["m_pad"] * p["lpq"] * 512 <= (2 << 30) or p["splits"] * p["qgroups"] <= 512
 
@@ -38,10 +44,13 @@ def test_tile_depth_by_dimensionality(pkg):
 def test_headline_geometries(pkg):
     p = pkg.plan_filter(128, 65536, 1048576)                 # C3: one workgroup per CU, two ref ranges
     assert (p["qgroups"], p["splits"], p["slot_pts"], p["queries_per_wg"], p["lpq"]) == (128, 2, 64, 512, 2)
+    assert (p["share_thr"], p["tile_rec"]) == (0, 0)          # long streams: private thresholds, a record per score
     p = pkg.plan_filter(256, 131072, 2097152, bf16=True)     # C5: 16x16 tiles, four lists per query
-    assert (p["qgroups"], p["splits"], p["lpq"]) == (256, 1, 4)
+    assert (p["qgroups"], p["splits"], p["lpq"]) == (256, 1, 4) and (p["share_thr"], p["tile_rec"]) == (0, 0)
     p = pkg.plan_filter(16, 1024, 1048576)                   # the reference driver's 16-D sample: 16-deep tile
     assert (p["kt"], p["slot_pts"], p["qgroups"]) == (16, 512, 2) and p["qgroups"] * p["splits"] >= 256
+    assert (p["share_thr"], p["tile_rec"]) == (1, 1)          # 128 short streams: shared thresholds, a record per tile
+    assert pkg.plan_filter(16, 1024, 1048576, flags=pkg.NNS_RECORDS_PER_REF)["tile_rec"] == 0
     p = pkg.plan_filter(1024, 65536, 1048576, bf16=True)     # 1024-deep: 128 queries per workgroup, blocks of two slots
     assert (p["queries_per_wg"], p["slot_pts"]) == (128, 16) and p["slots_per_split"] % 2 == 0 and p["total_slots"] % 2 == 0
 
