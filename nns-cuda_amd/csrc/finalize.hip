@@ -29,6 +29,23 @@
 // keeps the lexicographic (distance, index) minimum == V0's result, ties included.
 // Lists that overflowed, NaN/INF/huge inputs (K2's max-|value| word) or an empty list
 // send the query to the exact scan over all refs (K1b) instead.
+//
+// fp32 evaluation.  tau above is real arithmetic; the kernels compute, in fp32 (u = 2^-24, every operation
+// rounded to nearest, nothing contracted),
+//     tau_fl(a) = fl(c0 + fl(c1 * max(fl(a + x2), 0)))        K5:     T5(a) = fl(a + tau_fl(a))
+//                                                              filter: Tf(t) = fl(t + fl(1.002 * tau_fl(t)))
+// with c0 = 1.001 (2 + c1)(e3 + e2) + er, c1 = 1.001 * 2g/(1-g), x2 >= X^2 (tau_consts, then rounded UP to fp32).
+//  (i)  tau_fl(a) >= tau_c(a) (1 - 3u), tau_c = the same expression in real arithmetic: three roundings, each
+//       relative and downward by at most u.
+//  (ii) T5(a) >= a + tau_fl(a) - u |a + tau_fl(a)| >= a + tau_c(a) (1 - 4u) - u |a|: the rounding of the threshold
+//       sum is relative to the SCORE's magnitude, |a| <= max(X^2, Y^2 + 2XY) + e3 <= (X + Y)^2 + e3, i.e. up to
+//       tau / (2 (K + 2)) — 2.8 % of tau at K = 16.  The factors 1.001 do not cover that; er = 2u ((X+Y)^2 + e3 + e2)
+//       does: tau_c(a) - tau(a) >= 0.001 tau(a) + er, 0.001 tau >= 4u tau_c, er >= u |a|  ==>  T5(a) >= a + tau(a).
+//       So K5 keeps every member of C_i.  (tests/test_tau_model.py evaluates T5 in fp32 over a grid of depths, norms
+//       and scores and holds it against a + tau(a) in extended precision, and asserts slack >= u (|a| + tau).)
+//  (iii) every fp32 operation above is monotone non-decreasing in a, so t >= a ==> Tf(t) >= Tf(a), and
+//       fl(1.002 tau_fl) >= tau_fl gives Tf(a) >= T5(a): a lane's threshold — the minimum of Tf over the tile minima
+//       it has seen, all >= the query's final minimum a — never drops below T5(a); whatever K5 selects was recorded.
 #include "nns_internal.h"
 
 namespace nns {

@@ -210,7 +210,14 @@ __host__ __device__ inline TauConsts tau_consts(int kt, float qnorm2, float ymax
         }
     }
     const double c1 = 2.0 * gk / (1.0 - gk) * 1.001;
-    const double c0 = (2.0 + c1) * (e3 + e2) * 1.001 + 1e-30;
+    // er: the fp32 rounding of the THRESHOLD SUM itself.  K5 forms fl(a + tau_fl(a)) and the filter
+    // fl(t + fl(1.002 tau_fl(t))): one rounding of a sum whose magnitude is set by the score, not by tau —
+    // |a| <= max(X^2, Y^2 + 2XY) + e3 <= (X + Y)^2 + e3 — so it can pull the threshold down by u (|a| + tau),
+    // up to 1 / (2 (K + 2)) of tau itself (2.8 % at K = 16): more than the 0.1 % factors below absorb.  It gets a
+    // term of its own (2u instead of u: the evaluation of tau_fl — three more roundings, relative — and the
+    // rounding of the term itself ride on the spare u and on the 1.001 factors; finalize.hip, "fp32 evaluation").
+    const double er = 2.0 * u * ((X + Y) * (X + Y) + e3 + e2);
+    const double c0 = (2.0 + c1) * (e3 + e2) * 1.001 + er + 1e-30;
     TauConsts t;
     t.c0 = (float)(c0 * (1.0 + 1e-6));
     t.c1 = (float)(c1 * (1.0 + 1e-6));
