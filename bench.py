@@ -34,6 +34,13 @@ whole-call drop-in is reported in DESIGN.md, never here).
 At N = 1 the default run also measures, after the headline and outside its timed region, the
 other single-GPU configurations of BASELINE.json (C1, C2, C5) with the same fields: `also`.
 
+At N > 1 rank 0's line additionally says where a step's time went: `ranks` (per rank, gathered outside the
+timed region: wall ms per step up to the rank's own device idle, HIP-event ms of search and of the exchange,
+the slowest rank and rank 0's gap to it) and `exchange.exchange_ms`.  Every rendezvous step of a launched rank
+(process group, RCCL unique id, communicator, first all-reduce) runs under --rendezvous-timeout: a rank that
+waits longer names the step on stderr and exits non-zero.  Every cross-check of the line (`matches_*`, `same_*`,
+`verified_*`) is enforced: if one is false the line carries "parity_ok": false and the exit code is 3.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -397,8 +404,12 @@ def run_workload(ctx, name, steps, warmup, seed=1000):
         flops = 3.0 * k * m * n_local       # sub, mul, add per dim
         achieved = flops / (kern_ms * 1e-3) / 1e12
         traffic, tsrc = load_traffic(f"exact_{name}")
+        # V0's sub, mul, add (core.cu:41-42) must stay three roundings — nothing may fuse — so the kernel retires ONE flop
+        # per lane-instruction where the 157.3 TF vector peak counts an FMA's two: the reachable ceiling is half of it
         roof = {"bound": "valu", "kernel": "exact_lane_query_kernel", "achieved": achieved,
                 "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_VALU_TFLOPS,
+                "ceiling": PEAK_F32_VALU_TFLOPS / 2, "ceiling_frac": achieved / (PEAK_F32_VALU_TFLOPS / 2),
+                "ceiling_note": "non-FMA fp32 VALU rate (one flop per lane-instruction): V0's un-contracted arithmetic cannot use FMAs",
                 "kernel_ms": kern_ms, "flop_per_pair": 3 * k, "traffic": traffic,
                 "hbm_GBs_algorithmic": ((m + n_local) * k * 4 + 4 * m) / (kern_ms * 1e-3) / 1e9}
     if tsrc:

@@ -326,11 +326,11 @@ using OpBF16Wide = OpBF16T<16, 4, true, 4>;
 
 // OpBF16T32: v_mfma_f32_32x32x16_bf16 (the first version; kept for A/B builds with
 // -DNNS_BF16_TILE32): 16 bytes = 8 bf16 = one operand, lane = query, 16 refs per lane.
-template <int SPB_, int QB_, int NW_ = NNS_F_NW_BF16>
+template <int SPB_, int QB_, int NW_ = NNS_F_NW_BF16, bool LAG_ = (NW_ == 8)>
 struct OpBF16T32T {
     static constexpr int kSPB = SPB_;         // fragment steps (16 dims each) per 32-ref block
     static constexpr bool kTile16 = false;
-    static constexpr bool kLag = NW_ == 8;    // (one wave per SIMD has no partner to stagger against)
+    static constexpr bool kLag = LAG_;        // (one wave per SIMD has no partner to stagger against)
     static constexpr bool kTauInRegs = true;
     using Acc = AccSet;
     static constexpr int kQB = QB_;
@@ -352,6 +352,15 @@ using OpBF16K512 = OpBF16T32T<32, 1>;
 // step 0 of the even slot, retired at step 31 of the odd one.  One MFMA per 1 KiB LDS fragment, like the
 // 512-deep tile: LDS-bandwidth bound (~50 % of the bf16 MFMA peak), still ~50x the exact VALU scan.
 using OpBF16K1024 = OpBF16T32T<64, 1, 4>;
+// KT = 768 (512 < k <= 768; round 3): 48 fragment steps per block — two blocks over three ring slots.  The resident
+// operands of one query block are 192 registers, so — unlike at 1024 — TWO waves per SIMD fit (<= 256 registers
+// each): eight waves = 256 queries per workgroup, and a SIMD partner covers a wave's LDS-DMA issue stalls (the
+// one-wave-per-SIMD tiles lose about half their MFMA slots to them: profiles/r03_deep_ablate.txt).  Lock-step
+// partners (a half-block lag would straddle slots).
+#ifndef NNS_F_NW_K768
+#define NNS_F_NW_K768 8
+#endif
+using OpBF16K768 = OpBF16T32T<48, 1, NNS_F_NW_K768, false>;
 #if defined(NNS_BF16_WIDE)
 using OpBF16Active = OpBF16Wide;
 using OpBF16K512Active = OpBF16K512T;
@@ -405,13 +414,21 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
 {
     constexpr int F_NW = OP::kNW;
     constexpr int SPB = OP::kSPB;                      // fragment steps per image block
-    constexpr int SPBLK = SPB > 32 ? SPB / 32 : 1;     // ring slots per image block (2 at the 1024-deep tile)
-    constexpr int BPS = SPB > 32 ? 1 : 32 / SPB;       // image blocks per ring slot (a deep block: its slot's share)
+    // Blocks and ring slots: a slot is always 32 fragment steps.  Up to 32 steps per block a slot holds BPS whole
+    // blocks; deeper blocks straddle slots with a SUPER-PERIOD of SUP_SLOTS slots = SUP_BLKS blocks — 64 steps
+    // (1024-deep): 2 slots = 1 block; 48 steps (768-deep): 3 slots = 2 blocks, the second one starting in the middle
+    // of the second slot.  Accumulators carry across the slot barriers; every slot of a super-period brings the
+    // norms of all its blocks.
+    constexpr int SUP_SLOTS = SPB <= 32 ? 1 : (SPB == 64 ? 2 : 3);
+    constexpr int SUP_BLKS = SPB <= 32 ? 32 / SPB : SUP_SLOTS * 32 / SPB;
+    constexpr int SPBLK = SUP_SLOTS;                   // (name kept: slots of a deep block's super-period)
+    constexpr int BPS = SPB > 32 ? 1 : 32 / SPB;       // image blocks per ring slot (shallow tiles)
     constexpr int BLK_BYTES = SPB * 1024;
-    constexpr int SLOT_REFS = 32 * BPS;                // norms DMAed with a slot
+    constexpr int SLOT_REFS = 32 * SUP_BLKS;           // norms DMAed with a slot
     constexpr int F_PPW = F_SLOT_COORD / 1024 / F_NW;   // 1 KiB DMA pieces per wave per slot
-    static_assert((32 % SPB == 0 && SPB >= 2) || SPB == 64, "a slot is 32 fragment steps");
-    static_assert(SPBLK == 1 || (!OP::kLag && !OP::kTile16), "blocks spanning two slots: lock-step 32x32 tiles only");
+    static_assert((32 % SPB == 0 && SPB >= 2) || SPB == 64 || SPB == 48, "a slot is 32 fragment steps");
+    static_assert(SUP_SLOTS * 32 == SUP_BLKS * SPB, "a super-period is whole slots and whole blocks");
+    static_assert(SPBLK == 1 || (!OP::kLag && !OP::kTile16), "blocks straddling slots: lock-step 32x32 tiles only");
     static_assert(SLOT_REFS == 32 || SLOT_REFS == 64 || SLOT_REFS == 128 || SLOT_REFS == 256 || SLOT_REFS == 512,
                   "norm pieces: one dword per lane, or dwordx4 pieces of 256 norms");
     constexpr int F_NP = SLOT_REFS <= 256 ? 1 : SLOT_REFS / 256;   // norm DMA pieces per slot
@@ -854,7 +871,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     float4 fr[RING];
 
     auto frag_ptr = [&](const char *slot, int blk, int f) __attribute__((always_inline)) {
-        return (reinterpret_cast<const float4 *>(slot + blk * BLK_BYTES) + lane) + f * 64;
+        return (reinterpret_cast<const float4 *>(slot + (SPB <= 32 ? blk * BLK_BYTES : 0)) + lane) + f * 64;
     };
 
     using I0c = std::integral_constant<int, 0>;
@@ -865,21 +882,24 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         constexpr int DPH = decltype(dph_c)::value;   // DMA phase: the SIMD partners issue at different steps
         constexpr int HALF = decltype(half_c)::value; // blocks spanning two slots: which of them this interval is
         const bool first = s == 0;
-        const int blk0_global = SPBLK == 1 ? (slot0 + s) * BPS : (slot0 + s) / SPBLK;
+        // first block of this slot (shallow) / of this slot's super-period (deep: slot0 and ns are whole super-periods)
+        const int blk0_global = SPBLK == 1 ? (slot0 + s) * BPS : (slot0 + s) / SUP_SLOTS * SUP_BLKS;
         // compile-time schedule: step t works on position u = t - LAG * LAGOFF of the slot's
         // fragment stream (u < 0: tail of the previous slot; u >= 32: head of the next one)
         auto load = [&](auto tc_) __attribute__((always_inline)) {
             constexpr int t = decltype(tc_)::value;
             constexpr int u = t - LAG * LAGOFF;
-            if constexpr (u < 0) fr[t % RING] = *frag_ptr(prev, BPS - 1, SPB + u);
-            else if constexpr (u < 32) fr[t % RING] = *frag_ptr(cur, u / SPB, u % SPB);
-            else fr[t % RING] = *frag_ptr(nxt, (u - 32) / SPB, (u - 32) % SPB);   // (last interval: stale slot, unused)
+            // (fragment u of a slot sits at u KiB whatever the block depth: block * SPB + step = u)
+            if constexpr (u < 0) fr[t % RING] = *frag_ptr(prev, 0, 32 + u);
+            else if constexpr (u < 32) fr[t % RING] = *frag_ptr(cur, 0, u);
+            else fr[t % RING] = *frag_ptr(nxt, 0, u - 32);   // (last interval: stale slot, unused)
         };
         static_for<32>([&](auto tc_) __attribute__((always_inline)) {
             constexpr int t = decltype(tc_)::value;
             constexpr int u = t - LAG * LAGOFF;
-            constexpr int blk = u < 0 ? BPS - 1 : u / SPB;
-            constexpr int b = (u < 0 ? SPB + u : u % SPB) + 32 * HALF;   // operand / k position inside the block
+            // block (of the slot / of the super-period) and operand / k position inside it
+            constexpr int blk = SPBLK == 1 ? (u < 0 ? BPS - 1 : u / SPB) : (32 * HALF + u) / SPB;
+            constexpr int b = SPBLK == 1 ? (u < 0 ? SPB + u : u % SPB) : (32 * HALF + u) % SPB;
             load(std::integral_constant<int, t + PF>{});
             // one DMA piece per step, two slots ahead, in the MFMA shadow, at different steps
             // for the two SIMD partners (an LDS-DMA issue stalls the issuing wave ~100 cycles;
@@ -954,7 +974,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             if (lag) fr[tt % RING] = *frag_ptr(ring(-1), BPS - 1, SPB - LAGOFF + tt);
             else fr[tt % RING] = *frag_ptr(ring(0), 0, tt);
         } else {
-            fr[tt % RING] = *frag_ptr(ring(0), tt / SPB, tt % SPB);
+            fr[tt % RING] = *frag_ptr(ring(0), 0, tt);   // (slot-local fragment tt)
         }
     });
     // The slot loop, one copy per interval variant (the dispatch is wave-uniform and loop-invariant): with
@@ -979,6 +999,17 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                 interval(lag_c, dph_c, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
                 sync_slot();
                 interval(lag_c, dph_c, I1{}, s + 1, ring(s + 1), ring(s), ring(s + 2));
+            }
+        } else if constexpr (SPBLK == 3) {
+            // two 48-step blocks = three slots (ns is a multiple of 3: filter_plan): A 0..31 | A 32..47, B 0..15 | B 16..47
+            using I2 = std::integral_constant<int, 2>;
+            for (int s = 0; s < ns; s += 3) {
+                sync_slot();
+                interval(lag_c, dph_c, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
+                sync_slot();
+                interval(lag_c, dph_c, I1{}, s + 1, ring(s + 1), ring(s), ring(s + 2));
+                sync_slot();
+                interval(lag_c, dph_c, I2{}, s + 2, ring(s + 2), ring(s + 1), ring(s + 3));
             }
         } else {
             for (int s = 0; s < ns; ++s) {
@@ -1137,6 +1168,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed, bool 
         if (k <= 128) kt = 128;        // OpBF16K128: 4 k-steps per 16-ref tile, 4 blocks per slot
         else if (k <= 256) kt = 256;
         else if (k <= 512) kt = 512;   // OpBF16K512
+        else if (k <= 768) kt = 768;   // OpBF16K768: two 48-step blocks over three ring slots
         else if (k <= 1024) kt = 1024; // OpBF16K1024: K-split accumulation over two ring slots per block
     } else {
         if (k <= 16) kt = 16;          // OpF32K16: 2 fragment steps per block, 16 blocks per slot
@@ -1155,17 +1187,21 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed, bool 
     g->lpq = (bf16 && kt <= 512 && OpBF16Active::kTile16) ? 4 : 2;
     // queries per workgroup
     const int qw = 32 * (bf16 ? (kt == 1024  ? OpBF16K1024::kQB * OpBF16K1024::kNW
+                              : kt == 768 ? OpBF16K768::kQB * OpBF16K768::kNW
                               : kt == 512 ? OpBF16K512Active::kQB * OpBF16K512Active::kNW
                                           : OpBF16Active::kQB * OpBF16Active::kNW)
                               : (kt == 256 ? OpF32K256::kQB * OpF32K256::kNW : OpF32::kQB * OpF32::kNW));
     g->m_pad = divup(m, qw) * qw;
     // refs per ring slot (32 fragment steps of 8 fp32 / 16 bf16 dims)
     const int steps_per_block = bf16 ? kt / 16 : kt / 8;
-    const int slot_pts = steps_per_block <= 32 ? 32 * (32 / steps_per_block) : 32 / (steps_per_block / 32);
-    const int slots_per_block = steps_per_block <= 32 ? 1 : steps_per_block / 32;
-    const int pad_pts = slot_pts * slots_per_block;   // whole blocks
+    // deep blocks straddle slots: super-periods of `slots_per_block` slots = `pad_pts` refs (1024-deep: 2 slots = one
+    // block of 32; 768-deep: 3 slots = two blocks = 64 refs, i.e. 21.33 refs per slot — slot_pts, which only sizes
+    // paddings from here on, is rounded up)
+    const int slots_per_block = steps_per_block <= 32 ? 1 : (steps_per_block == 48 ? 3 : steps_per_block / 32);
+    const int pad_pts = steps_per_block <= 32 ? 32 * (32 / steps_per_block) : (steps_per_block == 48 ? 64 : 32);   // whole super-periods
+    const int slot_pts = steps_per_block <= 32 ? pad_pts : (pad_pts + slots_per_block - 1) / slots_per_block;
     g->n_pad = divup(n, pad_pts) * pad_pts;
-    g->total_slots = g->n_pad / slot_pts;
+    g->total_slots = g->n_pad / pad_pts * slots_per_block;
     g->qgroups = g->m_pad / qw;
     // One 8-wave workgroup is resident per CU (132 KiB of LDS), so the grid runs in rounds of
     // 256 workgroups and a round that is mostly empty costs as much as a full one.  Choose the
@@ -1198,7 +1234,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed, bool 
     // lanes, and record tiles instead of single scores; long streams (C3: 16384 tiles, C5: 8192) keep private
     // thresholds and per-score records.  Tile records need K5's one-wave-per-query form (splits >= 4: a tile's rows
     // are evaluated by 16 lanes side by side).
-    const int64_t stream_tiles = (int64_t)g->slots_per_split * (slot_pts / 32 > 0 ? slot_pts / 32 : 1) / (slots_per_block > 1 ? slots_per_block : 1);
+    const int64_t stream_tiles = (int64_t)g->slots_per_split / slots_per_block * (pad_pts / 32);
     g->share_thr = stream_tiles <= kShareThrMaxTiles ? 1 : 0;
     g->tile_rec = (stream_tiles <= kTileRecMaxTiles && g->splits >= 4 && !per_ref) ? 1 : 0;
 #ifdef NNS_F_NOSHARE   // (A/B builds)
@@ -1260,6 +1296,7 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
     const int rc = g.bf16 ? (g.kt == 128    ? launch_filter_t<OpBF16K128>(g, a, st)
                              : g.kt == 512  ? launch_filter_t<OpBF16K512Active>(g, a, st)
                              : g.kt == 1024 ? launch_filter_t<OpBF16K1024>(g, a, st)
+                             : g.kt == 768  ? launch_filter_t<OpBF16K768>(g, a, st)
                                            : launch_filter_t<OpBF16Active>(g, a, st))
                           : (g.kt == 16    ? launch_filter_t<OpF32K16>(g, a, st)
                              : g.kt == 32  ? launch_filter_t<OpF32K32>(g, a, st)

@@ -359,15 +359,16 @@ __global__ __launch_bounds__(256) void image_mixed512_kernel(int order, int k, i
 // fixed order).  T = float: centred by the mean, ONE rounding to bf16 (NNS_FILTER_BF16 / AUTO for fp32 points
 // beyond the fp32 tiles); T = uint16_t: bf16 bit patterns, no centring (a centred bf16 value would need a
 // second rounding).  Same values as image_mixed512_kernel / image_bf16_kernel would produce at their depths.
-template <int KT, typename T>
+// (KT = 768: three parts of 256 dims.)
+template <int KT, typename T, int HD = 512>
 __global__ __launch_bounds__(256) void image_deep_kernel(int k, int npts, const T *__restrict__ pts,
                                                          const float *__restrict__ mean, float scale, float pad_norm,
                                                          uint16_t *__restrict__ img, float *__restrict__ norms,
                                                          unsigned *__restrict__ max_norm_bits,
                                                          unsigned *__restrict__ maxabs_bits)
 {
-    static_assert(KT % 512 == 0, "halves of 512 dims");
-    constexpr int HD = 512, LD = HD + 8;
+    static_assert(KT % HD == 0 && HD % 64 == 0, "parts of HD dims, 8 threads per point");
+    constexpr int LD = HD + 8, TPD = HD / 8;   // dims per thread and part
     __shared__ __attribute__((aligned(16))) uint16_t tile[32 * LD];
     __shared__ double nrm[32][8];
     const int tid = threadIdx.x;
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void image_deep_kernel(int k, int npts, const 
     double acc = 0.0;
     uint4 *out = reinterpret_cast<uint4 *>(img + (size_t)blk * 32 * KT);
     for (int half = 0; half < KT / HD; ++half) {
-        for (int tt = part * 64; tt < part * 64 + 64; ++tt) {
+        for (int tt = part * TPD; tt < part * TPD + TPD; ++tt) {
             const int t = half * HD + tt;
             float c = 0.0f;
             if (live && t < k) {
@@ -438,11 +439,14 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, c
 {
     const int blocks = npts_pad / 32;
     if (out_bf16) {
-        if (kt != 1024 && kt != 512 && kt != 256 && kt != 128) {
-            set_error("prep: the bf16 operand image is 128, 256, 512 or 1024 deep (kt = %d)", kt);
+        if (kt != 1024 && kt != 768 && kt != 512 && kt != 256 && kt != 128) {
+            set_error("prep: the bf16 operand image is 128, 256, 512, 768 or 1024 deep (kt = %d)", kt);
             return NNS_ERR_UNSUPPORTED;
         }
-        if (kt == 1024)
+        if (kt == 768)
+            hipLaunchKernelGGL((image_deep_kernel<768, float, 256>), dim3(blocks), dim3(256), 0, st, k, npts, pts, mean, scale,
+                               pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
+        else if (kt == 1024)
             hipLaunchKernelGGL((image_deep_kernel<1024, float>), dim3(blocks), dim3(256), 0, st, k, npts, pts, mean, scale,
                                pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
         else if (kt == 512)
@@ -608,6 +612,9 @@ int launch_prep_image_bf16(int order, int kt, int k, int npts, int npts_pad, con
                            pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
     else if (kt == 1024 && order == 0)
         hipLaunchKernelGGL((image_deep_kernel<1024, uint16_t>), dim3(npts_pad / 32), dim3(256), 0, st, k, npts, pts,
+                           (const float *)nullptr, scale, pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
+    else if (kt == 768 && order == 0)
+        hipLaunchKernelGGL((image_deep_kernel<768, uint16_t, 256>), dim3(npts_pad / 32), dim3(256), 0, st, k, npts, pts,
                            (const float *)nullptr, scale, pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
     else if (kt == 128 && order == 1)
         hipLaunchKernelGGL(image_bf16_kernel<128>, dim3(npts_pad / 32), dim3(256), 0, st, order, k, npts, pts, scale,
