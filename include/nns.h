@@ -98,8 +98,9 @@ enum {
                           * of r[j * k + t]; queries stay [m][k].  The library transposes once on the
                           * device into a copy it owns. */
     NNS_RECORDS_PER_REF = 512, /* MFMA filter: keep the candidate records per SCORE (the form long reference streams
-                          * use) also on short streams, where AUTO records per (lane, ref tile) and lets K5 evaluate the
-                          * tile's rows — same results either way; lets tests and A/B runs drive both forms at any size */
+                          * use) also on short streams, where AUTO records ref TILES (a lane's two best tiles, or one
+                          * record per tile within its threshold) and lets K5 evaluate the tile's rows — same results
+                          * either way; lets tests and A/B runs drive both forms at any size */
     NNS_MULTI_FORCE_COLLECTIVE = 256 /* nns_search_*_multi, for tests: no single-GPU shortcut — even ONE shard runs the
                           * thread-per-GPU body, ncclCommInitAll and the grouped ncclAllReduce (core.cu:965-1057's
                           * shape), so that branch can be executed on a one-GPU box (a 1-rank all-reduce) */

@@ -724,6 +724,46 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         diag_cyc += __builtin_amdgcn_s_memtime() - diag_t0;
 #endif
     };
+    // ---- record form 2 (fp32 32 x 32 tiles on short ref streams): the lane's TWO BEST TILES, branch-free ---------
+    // A wave carries 32 queries per state and a query improves on its t-th tile with probability ~1/t, so on a stream
+    // of a few hundred tiles a third of the tiles took the threshold test's slow path in SOME lane (335 195 of
+    // 1 048 576 tile retirements at 1024 x 1 M x 16, ~800 cycles each with one record per tile, ~1400 with one per
+    // score: profiles/r03_streams.txt) — at the 16-deep tile, where a tile is 8 MFMAs, a quarter of the kernel.
+    // Short streams do not need lists at all: a lane keeps the minima of its best and second-best tile, where they
+    // came from, and the minimum of the third-best — 3 compares + 7 selects behind the tile's 8 v_min3, in the
+    // shadow of the SIMD partner's MFMAs, no branch, no store, no threshold.  At the end of the stream the lane writes
+    // three entries.  K5 takes a = the minimum over the entries and evaluates V0's distance for the rows of every
+    // recorded tile whose minimum is <= a + tau(a); if a lane's THIRD minimum is within the threshold too (three
+    // tiles of one lane's stream within tau: duplicates, or refs packed closer than the filter resolves) the query
+    // goes to the exact scan.  Completeness: tiles of a lane's stream with a minimum <= a + tau(a) are a prefix of
+    // its tiles sorted by minimum — of length <= 2 unless the third is inside too.
+    float m1[NS], m2[NS], m3[NS];
+    int t1[NS], t2[NS];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        m1[st] = m2[st] = m3[st] = __builtin_inff();
+        t1[st] = t2[st] = 0;
+    }
+    auto epilogue_top2 = [&](const typename OP::Acc &acc, int blk_global) __attribute__((always_inline)) {
+        if constexpr (!T16) {
+            static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
+                constexpr int st = decltype(st_c)::value;
+                const float tm = tile_min(acc, st_c);
+                // sorted insert of tm into m1 <= m2 <= m3 by min / max alone; the tile numbers follow with selects.
+                // (The old values go through empty asm statements: a select between two elements of these arrays is
+                //  otherwise rewritten by hipcc into a load through a selected POINTER, which keeps the arrays in scratch.)
+                float o1 = m1[st], o2 = m2[st];
+                int p1 = t1[st], p2 = t2[st];
+                asm volatile("" : "+v"(o1), "+v"(o2), "+v"(p1), "+v"(p2));
+                const bool lt1 = tm < o1, lt2 = tm < o2;   // strict: equal minima fill the next rank
+                m3[st] = fminf(m3[st], fmaxf(o2, tm));
+                m2[st] = fminf(o2, fmaxf(o1, tm));
+                m1[st] = fminf(o1, tm);
+                t2[st] = lt1 ? p1 : (lt2 ? blk_global : p2);
+                t1[st] = lt1 ? blk_global : p1;
+            });
+        }
+    };
     // record collection at the end of a ref block
     auto epilogue = [&](const typename OP::Acc &acc, int blk_global) __attribute__((always_inline)) {
         if constexpr ((kAblate & 2) != 0) {   // diagnostic: keep the accumulators alive, collect nothing
@@ -877,8 +917,9 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     using I0c = std::integral_constant<int, 0>;
     using I1c = std::integral_constant<int, 1>;
     // s: slot index relative to slot0; cur/prev/nxt: ring images of slots s, s-1, s+1
-    auto interval = [&](auto lag_c, auto dph_c, auto half_c, int s, const char *cur, const char *prev, const char *nxt) __attribute__((always_inline)) {
+    auto interval = [&](auto lag_c, auto dph_c, auto half_c, auto rec_c, int s, const char *cur, const char *prev, const char *nxt) __attribute__((always_inline)) {
         constexpr int LAG = decltype(lag_c)::value;
+        constexpr int REC2 = decltype(rec_c)::value;   // 1: record form 2 (the lane's two best tiles), 32 x 32 tiles only
         constexpr int DPH = decltype(dph_c)::value;   // DMA phase: the SIMD partners issue at different steps
         constexpr int HALF = decltype(half_c)::value; // blocks spanning two slots: which of them this interval is
         const bool first = s == 0;
@@ -936,7 +977,13 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             } else {
                 mma_all(acc, fr[t % RING], std::integral_constant<int, b>{});
                 if constexpr (b == SPB - 1) {                // the tile's epilogue right at its end
-                    if constexpr (u < 0) {
+                    if constexpr (REC2) {   // (a first interval's lagging half block chewed on garbage: skipped like below)
+                        if constexpr (u < 0) {
+                            if (!first) epilogue_top2(acc, blk0_global - 1);
+                        } else {
+                            epilogue_top2(acc, blk0_global + blk);
+                        }
+                    } else if constexpr (u < 0) {
                         if (!first) epilogue(acc, blk0_global - 1);
                     } else {
                         epilogue(acc, blk0_global + blk);
@@ -981,7 +1028,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // the three variants as branches inside ONE loop, hipcc parks the accumulators in different register
     // tuples at the merge and at the loop header and reconciles them with ~48 v_mov at every back-edge.
     // Every wave executes exactly ns barriers whichever copy it runs.
-    auto slot_loop = [&](auto lag_c, auto dph_c) __attribute__((always_inline)) {
+    auto slot_loop = [&](auto lag_c, auto dph_c, auto rec_c) __attribute__((always_inline)) {
         auto sync_slot = [&]() __attribute__((always_inline)) {
             if constexpr ((kAblate & 1) == 0) {
                 // my share of slot s+1 has landed.  AHEAD 2: issued an interval ago, the only DMA in flight.  AHEAD 3:
@@ -996,25 +1043,25 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             // a block = two slots (ns is even: filter_plan): even slot = k-steps 0..31, odd slot = 32..63
             for (int s = 0; s < ns; s += 2) {
                 sync_slot();
-                interval(lag_c, dph_c, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
+                interval(lag_c, dph_c, I0{}, rec_c, s, ring(s), ring(s - 1), ring(s + 1));
                 sync_slot();
-                interval(lag_c, dph_c, I1{}, s + 1, ring(s + 1), ring(s), ring(s + 2));
+                interval(lag_c, dph_c, I1{}, rec_c, s + 1, ring(s + 1), ring(s), ring(s + 2));
             }
         } else if constexpr (SPBLK == 3) {
             // two 48-step blocks = three slots (ns is a multiple of 3: filter_plan): A 0..31 | A 32..47, B 0..15 | B 16..47
             using I2 = std::integral_constant<int, 2>;
             for (int s = 0; s < ns; s += 3) {
                 sync_slot();
-                interval(lag_c, dph_c, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
+                interval(lag_c, dph_c, I0{}, rec_c, s, ring(s), ring(s - 1), ring(s + 1));
                 sync_slot();
-                interval(lag_c, dph_c, I1{}, s + 1, ring(s + 1), ring(s), ring(s + 2));
+                interval(lag_c, dph_c, I1{}, rec_c, s + 1, ring(s + 1), ring(s), ring(s + 2));
                 sync_slot();
-                interval(lag_c, dph_c, I2{}, s + 2, ring(s + 2), ring(s + 1), ring(s + 3));
+                interval(lag_c, dph_c, I2{}, rec_c, s + 2, ring(s + 2), ring(s + 1), ring(s + 3));
             }
         } else {
             for (int s = 0; s < ns; ++s) {
                 sync_slot();
-                interval(lag_c, dph_c, I0{}, s, ring(s), ring(s - 1), ring(s + 1));
+                interval(lag_c, dph_c, I0{}, rec_c, s, ring(s), ring(s - 1), ring(s + 1));
                 if constexpr (!OP::kLag) {
                     // lock-step partners (staggering only their DMA issue steps, or packing / spreading the
                     // pieces differently, measured +-0.5 % on C5).  The interval ends on the MFMAs that finish
@@ -1029,12 +1076,23 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             }
         }
     };
+    // (the record form, like the interval variant, is wave-uniform and loop-invariant: one copy of the loop each)
+    const bool top2 = !T16 && a.tile_rec == 2;
     if constexpr (OP::kLag) {
-        if (!half) slot_loop(I0{}, I0{});
-        else if (lag) slot_loop(I1{}, I1{});
-        else slot_loop(I0{}, I1{});
+        if (top2) {
+            if (!half) slot_loop(I0{}, I0{}, I1{});
+            else if (lag) slot_loop(I1{}, I1{}, I1{});
+            else slot_loop(I0{}, I1{}, I1{});
+        } else {
+            if (!half) slot_loop(I0{}, I0{}, I0{});
+            else if (lag) slot_loop(I1{}, I1{}, I0{});
+            else slot_loop(I0{}, I1{}, I0{});
+        }
+    } else if constexpr (!T16) {
+        if (top2) slot_loop(I0{}, I0{}, I1{});
+        else slot_loop(I0{}, I0{}, I0{});
     } else {
-        slot_loop(I0{}, I0{});
+        slot_loop(I0{}, I0{}, I0{});
     }
     if constexpr (T16) {   // ref tile 1 of the last block is still to be retired
         OP::mma16_tail_fence(acc);
@@ -1054,7 +1112,27 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             if constexpr (t + PF < LAGOFF) fr[(t + PF) % RING] = *frag_ptr(lastp, BPS - 1, SPB - LAGOFF + t + PF);
             mma_all(acc, fr[t % RING], std::integral_constant<int, SPB - LAGOFF + t>{});
         });
-        epilogue(acc, (slot0 + ns) * BPS - 1);
+        if (top2) epilogue_top2(acc, (slot0 + ns) * BPS - 1);
+        else epilogue(acc, (slot0 + ns) * BPS - 1);
+    }
+    if constexpr (!T16) if (top2) {
+        // record form 2: three entries per lane state — (best tile's minimum, first ref of the lane's rows of that tile),
+        // the same for the second best, and the third-best minimum alone (K5: within the threshold = exact scan)
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            CandEntry *const dst = reinterpret_cast<CandEntry *>(lbase + loff + (unsigned)(st * (kCandCap * 64 * (int)sizeof(CandEntry))));
+            CandEntry e;
+            e.s = m1[st];
+            e.j = t1[st] * 32 + 4 * h;
+            dst[0] = e;
+            e.s = m2[st];
+            e.j = t2[st] * 32 + 4 * h;
+            dst[64] = e;
+            e.s = m3[st];
+            e.j = 0;
+            dst[128] = e;
+            cnt[st] = 3;
+        }
     }
 #pragma unroll
     for (int st = 0; st < NS; ++st) a.counts[(lblk0 + st) * 64 + lane] = cnt[st];
@@ -1236,7 +1314,13 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed, bool 
     // are evaluated by 16 lanes side by side).
     const int64_t stream_tiles = (int64_t)g->slots_per_split / slots_per_block * (pad_pts / 32);
     g->share_thr = stream_tiles <= kShareThrMaxTiles ? 1 : 0;
-    g->tile_rec = (stream_tiles <= kTileRecMaxTiles && g->splits >= 4 && !per_ref) ? 1 : 0;
+    // record forms: 0 per score (long streams), 1 per (lane, ref tile) behind the threshold test (short streams, 16 x 16
+    // bf16 tiles: their epilogue has no vector slots to spare), 2 the lane's two best tiles, branch-free (short streams,
+    // 32 x 32 tiles: every fp32 depth and the 768- / 1024-deep bf16-operand tiles)
+    g->tile_rec = (stream_tiles <= kTileRecMaxTiles && g->splits >= 4 && !per_ref) ? (g->lpq == 4 ? 1 : 2) : 0;
+#ifdef NNS_F_NOTOP2
+    if (g->tile_rec == 2) g->tile_rec = 1;
+#endif
 #ifdef NNS_F_NOSHARE   // (A/B builds)
     g->share_thr = 0;
 #endif

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
         const float thr = a + tau_of(tc, a);
         const T *qi = q + (size_t)i * k;
         const bool vec = (k & 3) == 0 && (((uintptr_t)q | (uintptr_t)r) & (4 * sizeof(T) - 1)) == 0;
+        int over3 = 0;
         if (tile_rec) {
             // the lanes walk their lists in lockstep; an entry within the threshold is broadcast and its rows are
             // evaluated side by side, one lane per row (a V0 chain is sequential in t: the parallelism is over rows)
@@ -250,7 +251,13 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
                     ce.s = __builtin_inff();
                     ce.j = 0;
                     if (e < c) ce = lp[e * 64];
-                    const bool hit = e < c && ce.s <= thr;
+                    bool hit = e < c && ce.s <= thr;
+                    // record form 2: entry 2 is the lane's THIRD-best tile minimum, with no tile attached — inside
+                    // the threshold means more than two tiles of this lane's stream may hold V0's answer: exact scan
+                    if (tile_rec == 2 && e == 2) {
+                        if (hit) over3 = 1;
+                        hit = false;
+                    }
                     if (hit) ++ncand;   // (entries, i.e. tiles, within the threshold)
                     unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
                     while (mask) {      // (wave-uniform)
@@ -290,8 +297,9 @@ __global__ __launch_bounds__(256) void finalize_wave_kernel(
             const nns_key o = ((nns_key)hi << 32) | lo;
             best = o < best ? o : best;
             ncand += __shfl_xor(ncand, off, 64);
+            over3 |= __shfl_xor(over3, off, 64);
         }
-        if (best == NNS_KEY_NONE) fallback = true;
+        if (best == NNS_KEY_NONE || over3) fallback = true;
     }
     if (lane == 0) {
         keys[i] = fallback ? (nns_key)NNS_KEY_NONE : best;

@@ -156,7 +156,9 @@ struct FilterGeom {
     int slot_pts;         // refs per ring slot
     int share_thr;        // short ref streams: a query's lanes share their record thresholds
     int tile_rec;         // short ref streams: candidate entries are (tile minimum, first ref of the lane's rows of that
-                          // tile) — K5 evaluates all of the lane's rows — instead of (score, ref)
+                          // tile) — K5 evaluates all of the lane's rows — instead of (score, ref).  1: appended behind the
+                          // threshold test (16 x 16 tiles); 2: the lane's two best tiles + its third-best minimum,
+                          // tracked branch-free (32 x 32 tiles)
 };
 
 // One candidate of the filter: score s = |y'|^2 - 2 x'.y' and shard-local ref index.

@@ -54,7 +54,8 @@ def test_headline_geometries(pkg):
     assert (p["qgroups"], p["splits"], p["lpq"]) == (256, 1, 4) and (p["share_thr"], p["tile_rec"]) == (0, 0)
     p = pkg.plan_filter(16, 1024, 1048576)                   # the reference driver's 16-D sample: 16-deep tile
     assert (p["kt"], p["slot_pts"], p["qgroups"]) == (16, 512, 2) and p["qgroups"] * p["splits"] >= 256
-    assert (p["share_thr"], p["tile_rec"]) == (1, 1)          # 128 short streams: shared thresholds, a record per tile
+    assert (p["share_thr"], p["tile_rec"]) == (1, 2)          # 128 short streams, 32 x 32 tiles: the lane's two best tiles
+    assert pkg.plan_filter(256, 1024, 1048576, bf16=True)["tile_rec"] == 1      # 16 x 16 tiles: a record per tile, thresholds
     assert pkg.plan_filter(16, 1024, 1048576, flags=pkg.NNS_RECORDS_PER_REF)["tile_rec"] == 0
     p = pkg.plan_filter(1024, 65536, 1048576, bf16=True)     # 1024-deep: 128 queries per workgroup, blocks of two slots
     assert (p["queries_per_wg"], p["slot_pts"]) == (128, 16) and p["slots_per_split"] % 2 == 0 and p["total_slots"] % 2 == 0

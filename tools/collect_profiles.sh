@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box: bench lines, rocprofv3 kernel stats, PMC passes.
 # usage (from the repo root, on the GPU box): bash tools/collect_profiles.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -20,9 +20,21 @@ for W in c3 c5 c2; do
     echo "pmc $W $C exit $?"
   done
 done
+# K4 / K3: does the vector work co-execute with the matrix pipe?  (SQ_INSTS_VALU counts MFMAs too: 1.47 "VALU per MFMA"
+# on C5 = 0.47 other vector instructions per MFMA.)
+for W in c5 c3; do
+  D=$OUT/pmc_${W}_COEXEC
+  timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $D -- python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-also > $D.log 2>&1
+  echo "pmc $W COEXEC exit $?"
+done
+# the exact driver command under the profiler (headline + also block in one process)
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -- python3 bench.py > $OUT/stats_default.log 2>&1
+cp $OUT/stats_default/*/*kernel_stats.csv $OUT/kernel_stats_default.csv 2>/dev/null
 timeout -k 10 300 ./nns-cuda_amd/nns_driver --repeat 3 > $OUT/driver.txt 2>&1
 timeout -k 10 300 python tools/wholecall_c3.py 2>&1 | grep -v amdgpu > $OUT/wholecall_c3.txt
 timeout -k 10 300 python tools/probe_depths.py 2>&1 | grep -v amdgpu > $OUT/depths.txt
+timeout -k 10 300 python tools/probe_depths.py --deep 2>&1 | grep -v amdgpu > $OUT/depths_deep.txt
+timeout -k 10 200 python tools/probe_shapes.py 2>&1 | grep -v amdgpu > $OUT/shapes.txt
 timeout -k 10 300 python tools/probe_streams.py 2>&1 | grep -v amdgpu > $OUT/streams.txt
 cat $OUT/depths.txt
 ls $OUT
