@@ -749,15 +749,17 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             static_for<NS>([&](auto st_c) __attribute__((always_inline)) {
                 constexpr int st = decltype(st_c)::value;
                 const float tm = tile_min(acc, st_c);
-                // sorted insert of tm into m1 <= m2 <= m3 by min / max alone; the tile numbers follow with selects.
+                // sorted insert of tm into m1 <= m2 <= m3 by v_med3 / v_min; the tile numbers follow with selects.
                 // (The old values go through empty asm statements: a select between two elements of these arrays is
                 //  otherwise rewritten by hipcc into a load through a selected POINTER, which keeps the arrays in scratch.)
                 float o1 = m1[st], o2 = m2[st];
                 int p1 = t1[st], p2 = t2[st];
                 asm volatile("" : "+v"(o1), "+v"(o2), "+v"(p1), "+v"(p2));
                 const bool lt1 = tm < o1, lt2 = tm < o2;   // strict: equal minima fill the next rank
-                m3[st] = fminf(m3[st], fmaxf(o2, tm));
-                m2[st] = fminf(o2, fmaxf(o1, tm));
+                // (o1 <= o2 <= m3: the new second is the median of {tm, o1, o2}, the new third that of {tm, o2, m3}; scores
+                //  are finite or +INF, never NaN: K2 routes NaN inputs to the exact kernels)
+                m3[st] = __builtin_amdgcn_fmed3f(tm, o2, m3[st]);
+                m2[st] = __builtin_amdgcn_fmed3f(tm, o1, o2);
                 m1[st] = fminf(o1, tm);
                 t2[st] = lt1 ? p1 : (lt2 ? blk_global : p2);
                 t1[st] = lt1 ? blk_global : p1;

@@ -230,26 +230,31 @@ def test_filter_true_list_overflow_falls_back(pkg, orc):
     r = np.concatenate([base[:700], np.repeat(hot, 80000, axis=0), base[700:]])
     q = np.concatenate([hot + rng.normal(0, 1e-4, (24, k)).astype(np.float32), rng.random((40, k), dtype=np.float32)])
     _check(pkg, orc, q, r, paths=("mfma",), shards=(1, 2))
-    ix = pkg.Index(torch.from_numpy(r).cuda(), path="mfma_perref")    # a record per score: 80000 live candidates
-    idx = ix.search(torch.from_numpy(q).cuda())
-    st = ix.stats()
-    assert st["ambiguous"] >= 24, st
-    assert (idx[:24].cpu().numpy() == 700).all()
-    ix.close()
-    # a record per (lane, ref tile) — what a stream this short uses by itself — overflows only when more than 64
-    # TILES of one stream hold live candidates: 600000 duplicates over 256 streams
+    # every record form must notice that it cannot hold all live candidates and hand the query to the exact scan: a
+    # record per score (80000 live candidates against 64-entry rings), and the short-stream form of 32 x 32 tiles (a
+    # lane's two best tiles: here ~10 tiles of its stream hold copies of the nearest ref)
+    assert pkg.plan_filter(k, q.shape[0], r.shape[0])["tile_rec"] == 2
+    for path in ("mfma_perref", "mfma"):
+        ix = pkg.Index(torch.from_numpy(r).cuda(), path=path)
+        idx = ix.search(torch.from_numpy(q).cuda())
+        st = ix.stats()
+        assert st["ambiguous"] >= 24, (path, st)
+        assert (idx[:24].cpu().numpy() == 700).all()
+        ix.close()
+    # a record per (lane, ref tile) behind the threshold test — the short-stream form of the 16 x 16 bf16 tiles —
+    # overflows only when more than 64 TILES of one stream hold live candidates: 600000 duplicates over 256 streams
     k = 32
-    base = rng.random((2000, k), dtype=np.float32)
-    hot = rng.random((1, k), dtype=np.float32)
+    base = orc.round_bf16(rng.random((2000, k), dtype=np.float32))
+    hot = orc.round_bf16(rng.random((1, k), dtype=np.float32))
     r = np.concatenate([base[:700], np.repeat(hot, 600000, axis=0), base[700:]])
-    q = np.concatenate([hot + rng.normal(0, 1e-4, (24, k)).astype(np.float32), rng.random((40, k), dtype=np.float32)])
-    assert pkg.plan_filter(k, q.shape[0], r.shape[0])["tile_rec"] == 1
-    ix = pkg.Index(torch.from_numpy(r).cuda(), path="mfma")
-    idx = ix.search(torch.from_numpy(q).cuda())
+    q = orc.round_bf16(np.concatenate([hot + rng.normal(0, 1e-2, (24, k)).astype(np.float32), rng.random((40, k), dtype=np.float32)]))
+    assert pkg.plan_filter(k, q.shape[0], r.shape[0], bf16=True)["tile_rec"] == 1
+    ix = pkg.Index(torch.from_numpy(r).cuda().to(torch.bfloat16), path="mfma")
+    idx = ix.search(torch.from_numpy(q).cuda().to(torch.bfloat16))
     st = ix.stats()
     want_idx, _ = orc.v0_search(q, r, threads=8)
     assert np.array_equal(idx.cpu().numpy(), want_idx)
-    assert st["ambiguous"] >= 24 and (want_idx[:24] == 700).all(), st
+    assert st["ambiguous"] >= 20 and (want_idx[:24] == 700).sum() >= 20, st
     ix.close()
 
 
