@@ -1,10 +1,13 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box: bench lines, rocprofv3 kernel stats, PMC passes.
 # usage (from the repo root, on the GPU box): bash tools/collect_profiles.sh <tag>
+# (two parts, each within one gpurun call: part 1 = bench lines, kernel stats, PMC passes; part 2 = the rest)
 TAG=${1:-r03}
+PART=${2:-all}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+if [ "$PART" != "2" ]; then
 # the driver-shaped default run: C3 headline + the also block (C1, C2, C5)
 timeout -k 10 400 python bench.py --steps 10 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_default.json
 echo "bench default: $(cut -c1-160 $OUT/bench_default.json)"
@@ -20,6 +23,8 @@ for W in c3 c5 c2; do
     echo "pmc $W $C exit $?"
   done
 done
+fi
+if [ "$PART" = "1" ]; then ls $OUT; exit 0; fi
 # K4 / K3: does the vector work co-execute with the matrix pipe?  (SQ_INSTS_VALU counts MFMAs too: 1.47 "VALU per MFMA"
 # on C5 = 0.47 other vector instructions per MFMA.)
 for W in c5 c3; do
