@@ -908,6 +908,16 @@ __device__ __forceinline__ void stream_merge(const StreamMerge &mg, nns_key *key
 {
     const int tid = threadIdx.x;
     const int shard = blockIdx.x & (kStreamShards - 1);
+    if (gridDim.x == 1) {              // one workgroup (a short stream): its keys are the answer, no workspace involved
+        if (tid < mq) {
+            keys[tid] = mine;
+            if (mg.idx_out) {
+                mg.idx_out[tid] = (int)(uint32_t)(mine & 0xFFFFFFFFull);   // NNS_KEY_NONE -> 0, as V0
+                if (mg.dist_out) mg.dist_out[tid] = __uint_as_float((uint32_t)(mine >> 32));
+            }
+        }
+        return;
+    }
     if (tid < mq) {
         const nns_key old = __hip_atomic_fetch_min(&mg.acc[shard * kStreamMaxQ + tid], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("" ::"v"(old));   // returning atomic: its value back = it has been performed at the memory side
@@ -947,6 +957,12 @@ __device__ __forceinline__ void stream_merge(const StreamMerge &mg, nns_key *key
         if (tid >= 32 && tid <= 32 + kStreamShards)   // re-arm the counters (other lanes of the same wave)
             __hip_atomic_store(&mg.cnt[tid - 32], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+__global__ void stream_arm_kernel(nns_key *acc, int *cnt)
+{
+    if (threadIdx.x < kStreamShards * kStreamMaxQ) acc[threadIdx.x] = NNS_KEY_NONE;
+    if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
 }
 
 // lanes -> wave -> workgroup for QT queries; returns (threads qi < QT) the workgroup's key of query qi
@@ -1149,16 +1165,23 @@ static bool k1c_shape(int k, int m, const float *r)
     return (k == 4 || k == 8 || k == 16 || k == 32) && (((uintptr_t)r & 15) == 0);
 }
 
+// workgroups of a K1c launch
+static int k1c_workgroups(int k, int n)
+{
+    const int64_t pieces = k < 4 ? (int64_t)n : (int64_t)n * (k / 4);          // 16-byte pieces (k >= 4) or rows
+    int64_t wgs = divup64(divup64(pieces, 64 * NNS_K1C_U), NNS_K1C_NW);         // one tile per wave at least
+    if (wgs > NNS_K1C_WGS) wgs = NNS_K1C_WGS;
+    // up to four tiles per wave (128 KiB of refs in all) stay in ONE workgroup: no cross-workgroup merge, nothing to arm
+    if (wgs <= 4) wgs = 1;
+    return (int)wgs;
+}
+
 template <int QT>
 static int launch_k1c_q(int k, int m, int n, const float *q, const float *r, int64_t base, nns_key *keys, const StreamMerge &mg,
                         hipStream_t st)
 {
     constexpr int U = NNS_K1C_U, NW = NNS_K1C_NW;
-    const int64_t pieces = k < 4 ? (int64_t)n : (int64_t)n * (k / 4);          // 16-byte pieces (k >= 4) or rows
-    int64_t wgs = divup64(divup64(pieces, 64 * U), NW);                         // one tile per wave at least
-    if (wgs > NNS_K1C_WGS) wgs = NNS_K1C_WGS;
-    if (wgs < 1) wgs = 1;
-    const dim3 grid((unsigned)wgs), block(64 * NW);
+    const dim3 grid((unsigned)k1c_workgroups(k, n)), block(64 * NW);
     const float4 *r4 = reinterpret_cast<const float4 *>(r);
     switch (k) {
     case 1: hipLaunchKernelGGL((exact_stream_rows_kernel<1, QT, U, NW>), grid, block, 0, st, n, m, q, r, base, keys, mg); break;
@@ -1181,9 +1204,9 @@ static int launch_k1c(int k, int m, int n, const float *q, const float *r, int64
     mg.cnt = reinterpret_cast<int *>(ws + kStreamShards * kStreamMaxQ);
     mg.idx_out = idx_out;
     mg.dist_out = dist_out;
-    if (ws_fresh) {   // accumulators and counters re-arm themselves; a fresh workspace is armed once
-        NNS_TRY(launch_keys_fill(mg.acc, kStreamShards * kStreamMaxQ, NNS_KEY_NONE, st));
-        NNS_HIP(hipMemsetAsync(mg.cnt, 0, 16 * sizeof(int), st));
+    if (ws_fresh && k1c_workgroups(k, n) > 1) {   // accumulators and counters re-arm themselves; a fresh workspace is armed once
+        hipLaunchKernelGGL(stream_arm_kernel, dim3(1), dim3(64), 0, st, mg.acc, mg.cnt);
+        NNS_HIP(hipGetLastError());
     }
     if (m == 1) return launch_k1c_q<1>(k, m, n, q, r, base, keys, mg, st);
     if (m == 2) return launch_k1c_q<2>(k, m, n, q, r, base, keys, mg, st);

@@ -1315,7 +1315,10 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed, bool 
     // thresholds and per-score records.  Tile records need K5's one-wave-per-query form (splits >= 4: a tile's rows
     // are evaluated by 16 lanes side by side).
     const int64_t stream_tiles = (int64_t)g->slots_per_split / slots_per_block * (pad_pts / 32);
-    g->share_thr = stream_tiles <= kShareThrMaxTiles ? 1 : 0;
+    // (fp32 points through bf16 operands: the rounding term makes tau ~2^-6 |x'||y'|, thousands of refs lie within it
+    //  of the running minimum, and private thresholds fill the 64-entry rings — 5 504 of 65 536 queries overflowed into
+    //  the exact scan at k = 1024 — so their lanes always share, whatever the stream length)
+    g->share_thr = (stream_tiles <= kShareThrMaxTiles || mixed) ? 1 : 0;
     // record forms: 0 per score (long streams), 1 per (lane, ref tile) behind the threshold test (short streams, 16 x 16
     // bf16 tiles: their epilogue has no vector slots to spare), 2 the lane's two best tiles, branch-free (short streams,
     // 32 x 32 tiles: every fp32 depth and the 768- / 1024-deep bf16-operand tiles)

@@ -193,7 +193,13 @@ int nns_device_count(void)
     return cnt;
 }
 
-int nns_index_destroy(nns_index *ix)
+// stream_idle: the caller has just waited for the stream the index worked on (the whole-call paths): the workspaces are
+// reusable at once, no event needed
+static int index_destroy_impl(nns_index *ix, bool stream_idle);
+
+int nns_index_destroy(nns_index *ix) { return index_destroy_impl(ix, false); }
+
+static int index_destroy_impl(nns_index *ix, bool stream_idle)
 {
     if (!ix) return NNS_OK;
     DeviceScope keep_device;
@@ -203,7 +209,10 @@ int nns_index_destroy(nns_index *ix)
     // index's own, still running) are not waited for.  (Round 2: hipDeviceSynchronize() here.)
     void *const blocks[] = {ix->r_own, ix->rimg, ix->rnorm, ix->mean, ix->mean_ws, ix->scal, ix->qimg, ix->qnorm,
                             ix->lists, ix->counts, ix->amb_list, ix->multi_list, ix->exact_ws};
-    pool_free_after(blocks, (int)(sizeof(blocks) / sizeof(blocks[0])), ix->last_stream);
+    if (stream_idle)
+        for (void *b : blocks) pool_free(b);
+    else
+        pool_free_after(blocks, (int)(sizeof(blocks) / sizeof(blocks[0])), ix->last_stream);
     if (ix->ev_valid)
         for (int r = 0; r < kEvRing; ++r)
             for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ix->evr[r][i]);
@@ -822,8 +831,9 @@ static int search_host_small(int k, int m, int n, const void *s_points, const vo
     } while (0);
     // (rc == NNS_OK: the stream was synchronised above and everything is reusable at once; on an error path the
     //  blocks wait behind an event on the stream)
-    if (ix) nns_index_destroy(ix);
-    pool_free_after(blk, st);
+    if (ix) index_destroy_impl(ix, rc == NNS_OK);
+    if (rc == NNS_OK) pool_free(blk);
+    else pool_free_after(blk, st);
     lib_stream_release(st);
     return rc;
 }
@@ -910,7 +920,7 @@ static int search_range_overlapped_impl(int device, int k, int m, int n, const v
     if (rc == NNS_OK && hipStreamSynchronize(st) != hipSuccess) rc = NNS_ERR_HIP;
     if (rc == NNS_ERR_HIP) set_error("nns_search (chunked upload): %s", hipGetErrorString(hipGetLastError()));
     if (rc != NNS_OK) (void)hipStreamSynchronize(st);   // error paths: the caller frees r_d / keys right away
-    for (nns_index *ix : shards) nns_index_destroy(ix);   // (workspaces: behind an event on st)
+    for (nns_index *ix : shards) index_destroy_impl(ix, true);   // (the stream has been waited for on every path)
     lib_stream_release(st);
     return rc;
 }
@@ -1063,11 +1073,13 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             rc = num_shards == 1 ? index_search_impl(ix, m, q_d, bf16, keys, st, idx_d, dist_d)
                                  : index_search_impl(ix, m, q_d, bf16, first ? keys : keys_tmp, st);
             if (rc == NNS_OK && !first) rc = nns_keys_min(keys, keys_tmp, m, st);
+            bool idle = rc == NNS_OK;
             if (rc == NNS_OK && hipStreamSynchronize(st) != hipSuccess) {
                 set_error("nns_search_f32: kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
                 rc = NNS_ERR_HIP;
+                idle = false;
             }
-            nns_index_destroy(ix);
+            index_destroy_impl(ix, idle);
             ix = nullptr;
             first = false;
         }
