@@ -1040,6 +1040,10 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             rc = NNS_ERR_NOMEM;
             break;
         }
+        // Everything of this call on the ONE library stream — uploads, kernels, downloads (the caller's pageable
+        // buffers stay valid until the wait below): copies on the default stream + kernels on the library's stream
+        // meant an event edge between two hardware queues on either side of the search, 45 us of a 60 us call.
+#ifdef NNS_PLAIN_SYNC_COPIES   // (A/B builds: synchronous copies on the default stream, event edge to the kernels)
         if (hipMemcpy(q_d, s_points, qb, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(r_d, r_points, rb, hipMemcpyHostToDevice) != hipSuccess) {
             set_error("nns_search_f32: H2D copy failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1047,6 +1051,14 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             break;
         }
         if ((rc = order_after_default_stream(st)) != NNS_OK) break;   // uploads -> kernels
+#else
+        if (hipMemcpyAsync(q_d, s_points, qb, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(r_d, r_points, rb, hipMemcpyHostToDevice, st) != hipSuccess) {
+            set_error("nns_search_f32: H2D copy failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = NNS_ERR_HIP;
+            break;
+        }
+#endif
         if (flags & NNS_REFS_SOA) {
             // dimension-major refs: transpose once on the device, then shard the point-major copy
             if (pool_alloc(&r_t, rb) != hipSuccess) {
@@ -1073,6 +1085,9 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             rc = num_shards == 1 ? index_search_impl(ix, m, q_d, bf16, keys, st, idx_d, dist_d)
                                  : index_search_impl(ix, m, q_d, bf16, first ? keys : keys_tmp, st);
             if (rc == NNS_OK && !first) rc = nns_keys_min(keys, keys_tmp, m, st);
+            // (ONE shard: the index lives until the wait that comes with the download, below)
+            if (num_shards == 1) break;
+            // several shards: each is waited for before its index goes
             bool idle = rc == NNS_OK;
             if (rc == NNS_OK && hipStreamSynchronize(st) != hipSuccess) {
                 set_error("nns_search_f32: kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1084,19 +1099,17 @@ static int search_host_impl(int k, int m, int n, const void *s_points, const voi
             first = false;
         }
         if (rc != NNS_OK) break;
-        if (num_shards > 1) {
-            rc = nns_keys_unpack(keys, m, idx_d, dist_d, st);
-            if (rc == NNS_OK && hipStreamSynchronize(st) != hipSuccess) rc = NNS_ERR_HIP;
-        }
+        if (num_shards > 1) rc = nns_keys_unpack(keys, m, idx_d, dist_d, st);
         if (rc != NNS_OK) break;
-        if (hipMemcpy(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
-            (dist_out && hipMemcpy(dist_out, dist_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
-            set_error("nns_search_f32: D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
+        if (hipMemcpyAsync(idx_out, idx_d, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            (dist_out && hipMemcpyAsync(dist_out, dist_d, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess) ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            set_error("nns_search_f32: kernel execution or D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
             rc = NNS_ERR_HIP;
         }
     } while (0);
-    // success: every shard's stream work was waited for above; error paths: behind an event on the stream
-    if (ix) nns_index_destroy(ix);
+    // success: the stream was waited for with the download; error paths: behind an event on the stream
+    if (ix) index_destroy_impl(ix, rc == NNS_OK);
     void *const blocks[] = {q_d, r_d, r_t, keys, keys_tmp, idx_d, dist_d};
     if (rc == NNS_OK) for (void *b : blocks) pool_free(b);
     else pool_free_after(blocks, 7, st);
