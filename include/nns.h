@@ -48,8 +48,10 @@
  *     their device blocks back to the library's pool behind an EVENT on the stream that used them, read-outs
  *     (nns_index_stats, nns_index_near_ties) wait for the index's own stream, and the whole-call entry points
  *     run their kernels on a non-blocking stream of the library.  Kernels the application has running on
- *     other streams are never waited for.  (The stream an index last worked on must still exist when the
- *     index is destroyed; if it does not, destroy falls back to waiting for the device.)
+ *     other streams are never waited for by the library.  (The stream an index last worked on must still exist
+ *     when the index is destroyed; if it does not, destroy falls back to waiting for the device.  The HIP runtime
+ *     multiplexes streams onto a few hardware queues: work that lands on the queue of a long-running foreign kernel
+ *     runs behind it whatever a library does.)
  *   - every entry point that selects a device restores the caller's current device before it returns.
  */
 #ifndef NNS_MI355X_H

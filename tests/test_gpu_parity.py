@@ -1625,18 +1625,28 @@ def test_library_never_waits_for_foreign_streams(pkg, orc):
 
     work()                                   # warm: code objects, pool, pinned scratch, library streams
     torch.cuda.synchronize()
-    side = torch.cuda.Stream()               # torch's side streams are hipStreamNonBlocking
-    done = torch.cuda.Event()
-    with torch.cuda.stream(side):
-        torch.cuda._sleep(int(12e9))         # a foreign kernel that spins for ~5 s
-        done.record()
-    marks.clear()
-    work()
-    still_running = not done.query()
-    side.synchronize()
-    spans = [(n1, round(1e3 * (t1 - t0), 2)) for (n0, t0), (n1, t1) in zip(marks, marks[1:])]
-    assert still_running, f"the library waited for the application's stream; ms per operation: {spans}"
-    assert marks[-1][1] - marks[0][1] < 3.0, spans
+    # The runtime multiplexes HIP streams onto a few hardware queues (four by default), and work behind the foreign
+    # kernel on ITS queue waits for it whatever a library does: which of torch's pooled side streams shares a queue
+    # with one of the library's streams is the runtime's business.  A device-wide synchronisation, on the other hand,
+    # waits for EVERY foreign stream.  So: up to four foreign streams in turn (consecutive pool streams land on
+    # different queues); the library is clean if for at least one of them nothing waited.
+    outcomes = []
+    for attempt in range(4):
+        side = torch.cuda.Stream()           # torch's side streams are hipStreamNonBlocking
+        done = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(int(4e9))      # a foreign kernel that spins for ~1.7 s
+            done.record()
+        marks.clear()
+        work()
+        still_running = not done.query()
+        side.synchronize()
+        spans = [(n1, round(1e3 * (t1 - t0), 2)) for (n0, t0), (n1, t1) in zip(marks, marks[1:])]
+        outcomes.append((still_running, round(marks[-1][1] - marks[0][1], 3), spans))
+        if still_running and marks[-1][1] - marks[0][1] < 1.0:
+            break
+    assert any(ok and dt < 1.0 for ok, dt, _ in outcomes), \
+        f"the library waited for the application's stream on every attempt; (still running, seconds, ms per operation): {outcomes}"
 
 
 def test_entry_points_restore_the_current_device(pkg, orc):
