@@ -54,6 +54,24 @@ def test_default_bench_line_contract():
         assert also["c3x"]["same_indices_as_c3"] is True and "opt-in" in also["c3x"]["note"]
 
 
+def test_round3_line_contract():
+    """The same contract on this round's record, plus the fields round 3 added: the non-FMA ceiling of the exact
+    kernel and the enforced cross-checks."""
+    d = _line("r03_bench_default.json")
+    assert d["metric"] == "query-point-pairs/s" and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    _check_entry(d, 65536, 1048576, 128, 157.3)
+    assert d["parity_ok"] is True and "parity_failed" not in d
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["matches_gpu_indices"] is True
+    also = d["also"]
+    _check_entry(also["c2"], 4096, 65536, 3, 157.3)
+    _check_entry(also["c5"], 131072, 2097152, 256, 2500.0)
+    r2 = also["c2"]["roofline"]
+    assert r2["ceiling"] == pytest.approx(157.3 / 2) and r2["ceiling_frac"] == pytest.approx(2 * r2["frac"], rel=1e-9)
+    assert also["c3x"]["same_indices_as_c3"] is True
+    for name in ("c1", "c2"):
+        assert also[name]["unprofiled"]["same_indices"] is True
+
+
 def test_second_run_carries_unprofiled_fields():
     d = _line("r02_bench_default_run2.json")
     for name in ("c1", "c2"):

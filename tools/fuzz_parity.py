@@ -60,8 +60,9 @@ def main():
     cases = fails = 0
     last = t0
     while time.time() - t0 < a.seconds:
-        k = int(rng.choice([1, 2, 3, 4, 7, 8, 15, 16, 17, 31, 32, 33, 64, 65, 100, 128, 129, 200, 256, 257, 300, 400, 512, 513, 600, 777, 1024, 1025]))
-        m = int(rng.choice([1, 2, 31, 63, 64, 65, 255, 512, 513, 1000, 2049]))
+        k = int(rng.choice([1, 2, 3, 4, 7, 8, 15, 16, 17, 31, 32, 33, 64, 65, 100, 128, 129, 200, 256, 257, 300, 400, 512, 513, 600, 700,
+                            768, 769, 777, 1024, 1025]))
+        m = int(rng.choice([1, 2, 3, 4, 5, 31, 63, 64, 65, 255, 512, 513, 1000, 2049]))
         n = int(rng.choice([1, 5, 31, 64, 65, 257, 1000, 4097, 20001, 70000, 150000]))
         while float(m) * n * k > a.max_pairs * 64:
             n = max(1, n // 2)
@@ -71,8 +72,9 @@ def main():
             n += int(rng.integers(0, 1000))
         fam = str(rng.choice(families))
         bf16 = bool(rng.integers(0, 3) == 0) and fam not in ("huge",)
-        path = str(rng.choice(["auto", "auto", "mfma", "exact"]))
-        if path == "mfma" and k > (1024 if bf16 else 256):
+        # ("mfma_perref": the long-stream record form of the filter forced at any size, NNS_RECORDS_PER_REF)
+        path = str(rng.choice(["auto", "auto", "mfma", "mfma_perref", "exact"]))
+        if path.startswith("mfma") and k > (1024 if bf16 else 256):
             path = "auto"
         shards = int(rng.choice([1, 1, 2, 3]))
         # opt-in bf16 filter on fp32 points (NNS_FILTER_BF16): same answers required
