@@ -466,8 +466,12 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         for (int st = 0; st < NS; ++st) {
 #pragma unroll
             for (int b = 0; b < NBQ; ++b) bq[st][b] = src[(st * NBQ + b) * 64];
-            tc[st] = tau_consts(a.kt, a.qnorm[qblk0 * 32 + st * QPS + (lane & (QPS - 1))],
-                                __uint_as_float(a.scal->ymax2_bits), a.bf16);
+            // (record form 2 keeps no thresholds: skip the margin's double-precision arithmetic, ~1 us of a short stream)
+            if (T16 || a.tile_rec != 2)
+                tc[st] = tau_consts(a.kt, a.qnorm[qblk0 * 32 + st * QPS + (lane & (QPS - 1))],
+                                    __uint_as_float(a.scal->ymax2_bits), a.bf16);
+            else
+                tc[st] = TauConsts{0.0f, 0.0f, 0.0f};
         }
     }
     // Pin the loads here: hipcc must wait for them BEFORE the ring starts, not with a
@@ -575,6 +579,37 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                 acc.template at<qb>()[4 * g + 3] = nv.w;
             });
         }
+        }
+    };
+    // Shallow lock-step tiles (KT = 16: a tile is two steps, and both SIMD partners reach their tile boundaries
+    // together): the NEXT tile's norms are read a whole tile ahead into 16 registers, so the tile's first MFMA does not
+    // wait for an LDS round trip every 8 MFMAs (at the deeper tiles the lagging partner's MFMA chain covers it).
+#ifndef NNS_F_SEED_AHEAD
+#define NNS_F_SEED_AHEAD 1
+#endif
+    constexpr bool kSeedAhead = NNS_F_SEED_AHEAD && !T16 && !OP::kLag && SPB <= 4;
+    float4 nsd[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) nsd[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto seed_fetch = [&](const char *slot, int blk) __attribute__((always_inline)) {
+        if constexpr (kSeedAhead) {
+            const float *nrm = reinterpret_cast<const float *>(slot + F_SLOT_COORD) + blk * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) nsd[g] = *reinterpret_cast<const float4 *>(nrm + 8 * g);
+        }
+    };
+    auto seed_apply = [&](typename OP::Acc &acc) __attribute__((always_inline)) {
+        if constexpr (kSeedAhead) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                static_for<QB>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int qb = decltype(qc)::value;
+                    acc.template at<qb>()[4 * g + 0] = nsd[g].x;
+                    acc.template at<qb>()[4 * g + 1] = nsd[g].y;
+                    acc.template at<qb>()[4 * g + 2] = nsd[g].z;
+                    acc.template at<qb>()[4 * g + 3] = nsd[g].w;
+                });
+            }
         }
     };
     // 16x16 tiles: the norms of ref tile rt of block blk (rows 16 rt + 4 (lane >> 4) + i), loaded
@@ -971,7 +1006,14 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                 // slot after the slot's last block: confirmed by this interval's barrier)
                 if constexpr (b == SPB / 2 - 2) seed16(cur, blk, I1c{});
                 if constexpr (b == SPB - 2) seed16(blk + 1 < BPS ? cur : nxt, (blk + 1) % BPS, I0c{});
-            } else if constexpr (b == 0) seed(acc, cur, blk);   // a tile is seeded right where it starts
+            } else if constexpr (b == 0) {   // a tile is seeded right where it starts
+                if constexpr (kSeedAhead) {
+                    seed_apply(acc);   // (read a tile ago; the next tile's: block blk + 1 of this slot, or the next slot's first —
+                    seed_fetch(blk + 1 < BPS ? cur : nxt, (blk + 1) % BPS);   // landed and confirmed by this interval's barrier)
+                } else {
+                    seed(acc, cur, blk);
+                }
+            }
             // (LAG 1, very first interval: its first LAGOFF steps chew on a not-yet-written ring
             //  slot; that accumulator is discarded below and re-seeded at the next tile)
             if constexpr (T16) {
@@ -1016,6 +1058,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * F_PPS) : "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (T16) seed16(ring(0), 0, I0c{});   // the first block's tile-0 norms
+    seed_fetch(ring(0), 0);                          // (shallow lock-step tiles: the first tile's norms)
     // (LAG 1 reads ring slot -1 here: garbage in, discarded — see the interval)
     static_for<PF>([&](auto t) __attribute__((always_inline)) {
         constexpr int tt = decltype(t)::value;
