@@ -46,15 +46,16 @@ static const int kMaxPoints = NNS_MAX_POINTS;
 // synchronising read-back of K2's max-|value| word; K5's device-side check then covers NaN / INF / huge refs
 static const unsigned kCreateNoSync = 1u << 30;
 // ... and a small problem in a dimensionality the lane-per-query exact kernel is instantiated for (8, 16)
-// is faster there than through the filter's fixed costs (K2 on both clouds, filter ramp, K5: ~55 us):
-// the reference driver's 16-D 1024 x 1024 sample (main.cu:44) takes 9 us instead of 57.  Crossovers measured with
-// the 8-wave K1a (tools/probe_crossover.py, profiles/r02_crossover.txt): 16-D 2^26 pairs 68 us either way (2^27:
-// 122 vs 95 us), 8-D 2^26 pairs 37 vs 64 us
+// is faster there than through the filter's fixed costs (K2 on both clouds, filter ramp, K5: ~35 us in round 3, ~55 in
+// round 2): the reference driver's 16-D 1024 x 1024 sample (main.cu:44) takes 9 us instead of 40.  Crossovers re-measured
+// with round 3's record forms and K5 (tools/probe_crossover.py, profiles/r03_crossover.txt): 16-D 2^25 pairs 41 us either
+// way, 2^26 50 (filter) vs 66 us — unless the refs are few (65536 x 1024: 110 vs 62 us: a stream of 1024 refs is all ramp);
+// 8-D 2^26 pairs 35 (exact) vs 48 us
 static bool small_exact(int k, int64_t m, int64_t n)
 {
     if (m < kTinyM) return false;
     if (k == 8) return m * n <= ((int64_t)1 << 27);
-    if (k == 16) return m * n <= ((int64_t)1 << 26);
+    if (k == 16) return m * n <= ((int64_t)1 << 25) || (n < 8192 && m * n <= ((int64_t)1 << 26));
     return false;
 }
 // deepest dimensionality the MFMA filter tiles (bf16 operands; fp32 operands: 256)
