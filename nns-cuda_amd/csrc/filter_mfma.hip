@@ -361,6 +361,8 @@ using OpBF16K1024 = OpBF16T32T<64, 1, 4>;
 #define NNS_F_NW_K768 8
 #endif
 using OpBF16K768 = OpBF16T32T<48, 1, NNS_F_NW_K768, false>;
+// KT = 640 (512 < k <= 640): 40 fragment steps per block — FOUR blocks over FIVE ring slots; 160 operand registers, eight waves
+using OpBF16K640 = OpBF16T32T<40, 1, 8, false>;
 #if defined(NNS_BF16_WIDE)
 using OpBF16Active = OpBF16Wide;
 using OpBF16K512Active = OpBF16K512T;
@@ -418,15 +420,16 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // blocks; deeper blocks straddle slots with a SUPER-PERIOD of SUP_SLOTS slots = SUP_BLKS blocks — 64 steps
     // (1024-deep): 2 slots = 1 block; 48 steps (768-deep): 3 slots = 2 blocks, the second one starting in the middle
     // of the second slot.  Accumulators carry across the slot barriers; every slot of a super-period brings the
-    // norms of all its blocks.
-    constexpr int SUP_SLOTS = SPB <= 32 ? 1 : (SPB == 64 ? 2 : 3);
-    constexpr int SUP_BLKS = SPB <= 32 ? 32 / SPB : SUP_SLOTS * 32 / SPB;
+    // norms of all its blocks.  In general lcm(SPB, 32) steps: 40 steps (640-deep) = 5 slots = 4 blocks.
+    constexpr int SUP_GCD = SPB % 32 == 0 ? 32 : (SPB % 16 == 0 ? 16 : (SPB % 8 == 0 ? 8 : 1));
+    constexpr int SUP_SLOTS = SPB <= 32 ? 1 : SPB / SUP_GCD;
+    constexpr int SUP_BLKS = SPB <= 32 ? 32 / SPB : 32 / SUP_GCD;
     constexpr int SPBLK = SUP_SLOTS;                   // (name kept: slots of a deep block's super-period)
     constexpr int BPS = SPB > 32 ? 1 : 32 / SPB;       // image blocks per ring slot (shallow tiles)
     constexpr int BLK_BYTES = SPB * 1024;
     constexpr int SLOT_REFS = 32 * SUP_BLKS;           // norms DMAed with a slot
     constexpr int F_PPW = F_SLOT_COORD / 1024 / F_NW;   // 1 KiB DMA pieces per wave per slot
-    static_assert((32 % SPB == 0 && SPB >= 2) || SPB == 64 || SPB == 48, "a slot is 32 fragment steps");
+    static_assert((32 % SPB == 0 && SPB >= 2) || SPB == 64 || SPB == 48 || SPB == 40, "a slot is 32 fragment steps");
     static_assert(SUP_SLOTS * 32 == SUP_BLKS * SPB, "a super-period is whole slots and whole blocks");
     static_assert(SPBLK == 1 || (!OP::kLag && !OP::kTile16), "blocks straddling slots: lock-step 32x32 tiles only");
     static_assert(SLOT_REFS == 32 || SLOT_REFS == 64 || SLOT_REFS == 128 || SLOT_REFS == 256 || SLOT_REFS == 512,
@@ -524,8 +527,8 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
             // wave's DMA count per slot identical; a 32-ref slot also copies the next slot's 32)
             dma4(a.rnorm + (gslot / SPBLK) * SLOT_REFS + lane, dst + F_SLOT_COORD);   // (a deep block: both its slots)
         } else {
-            const int np = p - F_PPW;             // 256 norms per piece
-            dma16(a.rnorm + gslot * SLOT_REFS + np * 256 + lane * 4, dst + F_SLOT_COORD + np * 1024);
+            const int np = p - F_PPW;             // 256 norms per piece (a deep block: its super-period's, + over-read)
+            dma16(a.rnorm + (gslot / SPBLK) * SLOT_REFS + np * 256 + lane * 4, dst + F_SLOT_COORD + np * 1024);
         }
     };
     auto issue = [&](int s) __attribute__((always_inline)) {
@@ -1092,16 +1095,15 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                 sync_slot();
                 interval(lag_c, dph_c, I1{}, rec_c, s + 1, ring(s + 1), ring(s), ring(s + 2));
             }
-        } else if constexpr (SPBLK == 3) {
-            // two 48-step blocks = three slots (ns is a multiple of 3: filter_plan): A 0..31 | A 32..47, B 0..15 | B 16..47
-            using I2 = std::integral_constant<int, 2>;
-            for (int s = 0; s < ns; s += 3) {
-                sync_slot();
-                interval(lag_c, dph_c, I0{}, rec_c, s, ring(s), ring(s - 1), ring(s + 1));
-                sync_slot();
-                interval(lag_c, dph_c, I1{}, rec_c, s + 1, ring(s + 1), ring(s), ring(s + 2));
-                sync_slot();
-                interval(lag_c, dph_c, I2{}, rec_c, s + 2, ring(s + 2), ring(s + 1), ring(s + 3));
+        } else if constexpr (SPBLK > 2) {
+            // a super-period of SPBLK slots (ns is a multiple of it: filter_plan) — 48-step blocks: A 0..31 | A 32..47,
+            // B 0..15 | B 16..47; 40-step blocks: four blocks over five slots
+            for (int s = 0; s < ns; s += SPBLK) {
+                static_for<SPBLK>([&](auto ph_c) __attribute__((always_inline)) {
+                    constexpr int ph = decltype(ph_c)::value;
+                    sync_slot();
+                    interval(lag_c, dph_c, ph_c, rec_c, s + ph, ring(s + ph), ring(s + ph - 1), ring(s + ph + 1));
+                });
             }
         } else {
             for (int s = 0; s < ns; ++s) {
@@ -1291,6 +1293,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed, bool 
         if (k <= 128) kt = 128;        // OpBF16K128: 4 k-steps per 16-ref tile, 4 blocks per slot
         else if (k <= 256) kt = 256;
         else if (k <= 512) kt = 512;   // OpBF16K512
+        else if (k <= 640) kt = 640;   // OpBF16K640: four 40-step blocks over five ring slots
         else if (k <= 768) kt = 768;   // OpBF16K768: two 48-step blocks over three ring slots
         else if (k <= 1024) kt = 1024; // OpBF16K1024: K-split accumulation over two ring slots per block
     } else {
@@ -1311,6 +1314,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed, bool 
     // queries per workgroup
     const int qw = 32 * (bf16 ? (kt == 1024  ? OpBF16K1024::kQB * OpBF16K1024::kNW
                               : kt == 768 ? OpBF16K768::kQB * OpBF16K768::kNW
+                              : kt == 640 ? OpBF16K640::kQB * OpBF16K640::kNW
                               : kt == 512 ? OpBF16K512Active::kQB * OpBF16K512Active::kNW
                                           : OpBF16Active::kQB * OpBF16Active::kNW)
                               : (kt == 256 ? OpF32K256::kQB * OpF32K256::kNW : OpF32::kQB * OpF32::kNW));
@@ -1320,8 +1324,9 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed, bool 
     // deep blocks straddle slots: super-periods of `slots_per_block` slots = `pad_pts` refs (1024-deep: 2 slots = one
     // block of 32; 768-deep: 3 slots = two blocks = 64 refs, i.e. 21.33 refs per slot — slot_pts, which only sizes
     // paddings from here on, is rounded up)
-    const int slots_per_block = steps_per_block <= 32 ? 1 : (steps_per_block == 48 ? 3 : steps_per_block / 32);
-    const int pad_pts = steps_per_block <= 32 ? 32 * (32 / steps_per_block) : (steps_per_block == 48 ? 64 : 32);   // whole super-periods
+    // (640-deep: 5 slots = four blocks = 128 refs)
+    const int slots_per_block = steps_per_block <= 32 ? 1 : (steps_per_block == 48 ? 3 : (steps_per_block == 40 ? 5 : steps_per_block / 32));
+    const int pad_pts = steps_per_block <= 32 ? 32 * (32 / steps_per_block) : (steps_per_block == 48 ? 64 : (steps_per_block == 40 ? 128 : 32));   // whole super-periods
     const int slot_pts = steps_per_block <= 32 ? pad_pts : (pad_pts + slots_per_block - 1) / slots_per_block;
     g->n_pad = divup(n, pad_pts) * pad_pts;
     g->total_slots = g->n_pad / pad_pts * slots_per_block;
@@ -1429,6 +1434,7 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
                              : g.kt == 512  ? launch_filter_t<OpBF16K512Active>(g, a, st)
                              : g.kt == 1024 ? launch_filter_t<OpBF16K1024>(g, a, st)
                              : g.kt == 768  ? launch_filter_t<OpBF16K768>(g, a, st)
+                             : g.kt == 640  ? launch_filter_t<OpBF16K640>(g, a, st)
                                            : launch_filter_t<OpBF16Active>(g, a, st))
                           : (g.kt == 16    ? launch_filter_t<OpF32K16>(g, a, st)
                              : g.kt == 32  ? launch_filter_t<OpF32K32>(g, a, st)

@@ -1136,13 +1136,13 @@ int nns_warmup(int device)
     NNS_TRY(ensure_device_ok(device));
     // (k, m, n, bf16, path): K1a (3-D and 16-D), K1b, the fp32 tile depths 16 / 32 / 64 / 128 / 256 (forced onto the
     // filter: AUTO keeps a 64 x 512 x 16 problem on the exact kernel), the bf16-operand tiles for fp32 points (512 /
-    // 768 / 1024: AUTO), the bf16 tiles 128 / 256 / 512 / 768 / 1024
+    // 640 / 768 / 1024: AUTO), the bf16 tiles 128 / 256 / 512 / 640 / 768 / 1024
     static const int shapes[][5] = {{3, 64, 512, 0, NNS_PATH_AUTO},    {16, 64, 512, 0, NNS_PATH_AUTO},  {16, 1, 512, 0, NNS_PATH_AUTO},
                                     {16, 64, 512, 0, NNS_PATH_MFMA},   {24, 64, 512, 0, NNS_PATH_MFMA},  {40, 64, 512, 0, NNS_PATH_MFMA},
                                     {100, 64, 512, 0, NNS_PATH_MFMA},  {200, 64, 512, 0, NNS_PATH_MFMA}, {300, 64, 512, 0, NNS_PATH_AUTO},
-                                    {600, 64, 512, 0, NNS_PATH_AUTO},  {800, 64, 512, 0, NNS_PATH_AUTO}, {64, 64, 512, 1, NNS_PATH_MFMA},
-                                    {200, 64, 512, 1, NNS_PATH_MFMA},  {300, 64, 512, 1, NNS_PATH_MFMA}, {600, 64, 512, 1, NNS_PATH_MFMA},
-                                    {800, 64, 512, 1, NNS_PATH_MFMA}};
+                                    {600, 64, 512, 0, NNS_PATH_AUTO},  {700, 64, 512, 0, NNS_PATH_AUTO}, {800, 64, 512, 0, NNS_PATH_AUTO},
+                                    {64, 64, 512, 1, NNS_PATH_MFMA},   {200, 64, 512, 1, NNS_PATH_MFMA}, {300, 64, 512, 1, NNS_PATH_MFMA},
+                                    {600, 64, 512, 1, NNS_PATH_MFMA},  {700, 64, 512, 1, NNS_PATH_MFMA}, {800, 64, 512, 1, NNS_PATH_MFMA}};
     const int kmax = 800, mmax = 64, nmax = 512;
     float *q = (float *)malloc(sizeof(float) * kmax * mmax), *r = (float *)malloc(sizeof(float) * kmax * nmax);
     int *idx = (int *)malloc(sizeof(int) * mmax);

@@ -86,7 +86,7 @@ def _bf16_model_cases(rng, kt):
 
 
 @pytest.mark.parametrize("shape", [2, 1])
-@pytest.mark.parametrize("kt", [128, 256, 512, 768, 1024])
+@pytest.mark.parametrize("kt", [128, 256, 512, 640, 768, 1024])
 def test_bf16_mfma_error_model(pkg, orc, shape, kt):
     """The bf16 MFMA's accumulation (fp32 accumulate, order and rounding undocumented) against fp64 on
     bf16-representable operands, at EVERY depth the product runs bf16 tiles (128 / 256 / 512 / 1024), for both
@@ -121,7 +121,7 @@ def test_bf16_mfma_error_model(pkg, orc, shape, kt):
     print(f"bf16 MFMA shape {shape} kt {kt}: worst error / e3 bound = {worst:.4f}")
 
 
-@pytest.mark.parametrize("kt", [128, 256, 512, 768, 1024])
+@pytest.mark.parametrize("kt", [128, 256, 512, 640, 768, 1024])
 def test_bf16_operand_rounding_model_mode2(pkg, orc, kt):
     """tau mode 2 (fp32 points, operands rounded to bf16, NNS_FILTER_BF16): the filter's score error
     against the UNROUNDED fp32 values — rounding bound 2^-6 (1 + 2^-8) |x'||y'| plus the accumulate
@@ -1142,12 +1142,14 @@ def test_whole_call_pipelined_upload(pkg, orc):
 
 
 @pytest.mark.parametrize("shape", [(300, 5000, 1024), (700, 20001, 600), (130, 3000, 800), (1100, 9000, 513),
-                                   (300, 5000, 768), (2049, 777, 700), (64, 33000, 769)])
+                                   (300, 5000, 768), (2049, 777, 700), (64, 33000, 769), (300, 5000, 640), (1100, 9000, 641),
+                                   (513, 40000, 550)])
 def test_k1024_tile_shapes(pkg, orc, shape):
     """512 < k <= 1024: K-split accumulation on the MFMA path — the 1024-deep bf16 tile (one query block per
     wave on one wave per SIMD, a 32-ref block spanning TWO ring slots with its accumulators carried across
     the slot barrier) and, up to k = 768, the 768-deep one (48 fragment steps per block: two blocks over THREE ring
-    slots, the second starting in the middle of a slot; two waves per SIMD).  bf16 points (forced and AUTO) and fp32 points (AUTO takes the bf16-operand filter with
+    slots, the second starting in the middle of a slot; two waves per SIMD) and, up to k = 640, the 640-deep one (40 steps per
+    block: four blocks over FIVE slots).  bf16 points (forced and AUTO) and fp32 points (AUTO takes the bf16-operand filter with
     the rounding-widened margin + exact fp32 re-rank): V0's bits, whole and sharded, exact duplicates and
     near-duplicates below bf16 resolution included; and faster than the exact VALU scan."""
     m, n, k = shape
@@ -1174,7 +1176,7 @@ def test_k1024_tile_shapes(pkg, orc, shape):
         ix = pkg.Index(rr, profile=True)
         ix.search(qq)
         st = ix.stats()
-        assert st["path"] == 2 and st["k_tile"] == (768 if k <= 768 else 1024), st
+        assert st["path"] == 2 and st["k_tile"] == (640 if k <= 640 else 768 if k <= 768 else 1024), st
         ix.close()
     with pytest.raises(pkg.NNSError):
         pkg.search(np.zeros((4, 1025), np.float32), np.zeros((9, 1025), np.float32), path="mfma", filter_bf16=True)

@@ -11,7 +11,7 @@ m, n = 65536, 1048576
 CASES = [(16, "f32"), (32, "f32"), (64, "f32"), (128, "f32"), (256, "f32"), (512, "f32"), (1024, "f32"),
          (128, "bf16"), (256, "bf16"), (512, "bf16"), (1024, "bf16")]
 if "--deep" in sys.argv:
-    CASES = [(1024, "f32"), (1024, "bf16"), (600, "bf16"), (768, "bf16"), (600, "f32")]
+    CASES = [(1024, "f32"), (1024, "bf16"), (600, "bf16"), (640, "bf16"), (768, "bf16"), (700, "bf16"), (600, "f32")]
 if "--k16" in sys.argv:     # the shallow fp32 tiles only
     CASES = [(16, "f32"), (32, "f32")]
 if "--nw4" in sys.argv:     # the one-wave-per-SIMD tiles only
