@@ -363,6 +363,9 @@ using OpBF16K1024 = OpBF16T32T<64, 1, 4>;
 using OpBF16K768 = OpBF16T32T<48, 1, NNS_F_NW_K768, false>;
 // KT = 640 (512 < k <= 640): 40 fragment steps per block — FOUR blocks over FIVE ring slots; 160 operand registers, eight waves
 using OpBF16K640 = OpBF16T32T<40, 1, 8, false>;
+// KT = 384 (256 < k <= 384, round 3): the same form below 512 — 24 steps per block, four blocks over three slots, 96 operand
+// registers; k = 300 ran on the 512-deep tile at 36 % of peak
+using OpBF16K384 = OpBF16T32T<24, 1, 8, false>;
 #if defined(NNS_BF16_WIDE)
 using OpBF16Active = OpBF16Wide;
 using OpBF16K512Active = OpBF16K512T;
@@ -422,14 +425,16 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // of the second slot.  Accumulators carry across the slot barriers; every slot of a super-period brings the
     // norms of all its blocks.  In general lcm(SPB, 32) steps: 40 steps (640-deep) = 5 slots = 4 blocks.
     constexpr int SUP_GCD = SPB % 32 == 0 ? 32 : (SPB % 16 == 0 ? 16 : (SPB % 8 == 0 ? 8 : 1));
-    constexpr int SUP_SLOTS = SPB <= 32 ? 1 : SPB / SUP_GCD;
-    constexpr int SUP_BLKS = SPB <= 32 ? 32 / SPB : 32 / SUP_GCD;
+    // (24 steps, 384-deep: 3 slots = 4 blocks.)  "Deep" = the block does not divide the slot.
+    constexpr bool DEEP = 32 % SPB != 0;
+    constexpr int SUP_SLOTS = DEEP ? SPB / SUP_GCD : 1;
+    constexpr int SUP_BLKS = DEEP ? 32 / SUP_GCD : 32 / SPB;
     constexpr int SPBLK = SUP_SLOTS;                   // (name kept: slots of a deep block's super-period)
-    constexpr int BPS = SPB > 32 ? 1 : 32 / SPB;       // image blocks per ring slot (shallow tiles)
+    constexpr int BPS = DEEP ? 1 : 32 / SPB;           // image blocks per ring slot (shallow tiles)
     constexpr int BLK_BYTES = SPB * 1024;
     constexpr int SLOT_REFS = 32 * SUP_BLKS;           // norms DMAed with a slot
     constexpr int F_PPW = F_SLOT_COORD / 1024 / F_NW;   // 1 KiB DMA pieces per wave per slot
-    static_assert((32 % SPB == 0 && SPB >= 2) || SPB == 64 || SPB == 48 || SPB == 40, "a slot is 32 fragment steps");
+    static_assert((32 % SPB == 0 && SPB >= 2) || SPB == 64 || SPB == 48 || SPB == 40 || SPB == 24, "a slot is 32 fragment steps");
     static_assert(SUP_SLOTS * 32 == SUP_BLKS * SPB, "a super-period is whole slots and whole blocks");
     static_assert(SPBLK == 1 || (!OP::kLag && !OP::kTile16), "blocks straddling slots: lock-step 32x32 tiles only");
     static_assert(SLOT_REFS == 32 || SLOT_REFS == 64 || SLOT_REFS == 128 || SLOT_REFS == 256 || SLOT_REFS == 512,
@@ -951,7 +956,7 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     float4 fr[RING];
 
     auto frag_ptr = [&](const char *slot, int blk, int f) __attribute__((always_inline)) {
-        return (reinterpret_cast<const float4 *>(slot + (SPB <= 32 ? blk * BLK_BYTES : 0)) + lane) + f * 64;
+        return (reinterpret_cast<const float4 *>(slot + (DEEP ? 0 : blk * BLK_BYTES)) + lane) + f * 64;
     };
 
     using I0c = std::integral_constant<int, 0>;
@@ -1292,6 +1297,7 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed, bool 
     if (bf16) {
         if (k <= 128) kt = 128;        // OpBF16K128: 4 k-steps per 16-ref tile, 4 blocks per slot
         else if (k <= 256) kt = 256;
+        else if (k <= 384) kt = 384;   // OpBF16K384: four 24-step blocks over three ring slots
         else if (k <= 512) kt = 512;   // OpBF16K512
         else if (k <= 640) kt = 640;   // OpBF16K640: four 40-step blocks over five ring slots
         else if (k <= 768) kt = 768;   // OpBF16K768: two 48-step blocks over three ring slots
@@ -1310,11 +1316,12 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed, bool 
     g->bf16 = bf16 ? 1 : 0;
     g->mixed = mixed ? 1 : 0;
     g->kt = kt;
-    g->lpq = (bf16 && kt <= 512 && OpBF16Active::kTile16) ? 4 : 2;
+    g->lpq = (bf16 && kt <= 512 && kt != 384 && OpBF16Active::kTile16) ? 4 : 2;
     // queries per workgroup
     const int qw = 32 * (bf16 ? (kt == 1024  ? OpBF16K1024::kQB * OpBF16K1024::kNW
                               : kt == 768 ? OpBF16K768::kQB * OpBF16K768::kNW
                               : kt == 640 ? OpBF16K640::kQB * OpBF16K640::kNW
+                              : kt == 384 ? OpBF16K384::kQB * OpBF16K384::kNW
                               : kt == 512 ? OpBF16K512Active::kQB * OpBF16K512Active::kNW
                                           : OpBF16Active::kQB * OpBF16Active::kNW)
                               : (kt == 256 ? OpF32K256::kQB * OpF32K256::kNW : OpF32::kQB * OpF32::kNW));
@@ -1324,10 +1331,12 @@ int filter_plan(int k, int m, int n, bool bf16, FilterGeom *g, bool mixed, bool 
     // deep blocks straddle slots: super-periods of `slots_per_block` slots = `pad_pts` refs (1024-deep: 2 slots = one
     // block of 32; 768-deep: 3 slots = two blocks = 64 refs, i.e. 21.33 refs per slot — slot_pts, which only sizes
     // paddings from here on, is rounded up)
-    // (640-deep: 5 slots = four blocks = 128 refs)
-    const int slots_per_block = steps_per_block <= 32 ? 1 : (steps_per_block == 48 ? 3 : (steps_per_block == 40 ? 5 : steps_per_block / 32));
-    const int pad_pts = steps_per_block <= 32 ? 32 * (32 / steps_per_block) : (steps_per_block == 48 ? 64 : (steps_per_block == 40 ? 128 : 32));   // whole super-periods
-    const int slot_pts = steps_per_block <= 32 ? pad_pts : (pad_pts + slots_per_block - 1) / slots_per_block;
+    // (640-deep: 5 slots = four blocks = 128 refs; 384-deep: 3 slots = four blocks = 128 refs)
+    const bool deep = 32 % steps_per_block != 0;
+    const int sup_gcd = steps_per_block % 32 == 0 ? 32 : (steps_per_block % 16 == 0 ? 16 : 8);
+    const int slots_per_block = deep ? steps_per_block / sup_gcd : 1;                         // slots of a super-period
+    const int pad_pts = deep ? 32 * (32 / sup_gcd) : 32 * (32 / steps_per_block);            // refs of a super-period: whole blocks
+    const int slot_pts = deep ? (pad_pts + slots_per_block - 1) / slots_per_block : pad_pts;
     g->n_pad = divup(n, pad_pts) * pad_pts;
     g->total_slots = g->n_pad / pad_pts * slots_per_block;
     g->qgroups = g->m_pad / qw;
@@ -1435,6 +1444,7 @@ int launch_filter(const FilterGeom &g, const void *qimg, const void *rimg, const
                              : g.kt == 1024 ? launch_filter_t<OpBF16K1024>(g, a, st)
                              : g.kt == 768  ? launch_filter_t<OpBF16K768>(g, a, st)
                              : g.kt == 640  ? launch_filter_t<OpBF16K640>(g, a, st)
+                             : g.kt == 384  ? launch_filter_t<OpBF16K384>(g, a, st)
                                            : launch_filter_t<OpBF16Active>(g, a, st))
                           : (g.kt == 16    ? launch_filter_t<OpF32K16>(g, a, st)
                              : g.kt == 32  ? launch_filter_t<OpF32K32>(g, a, st)

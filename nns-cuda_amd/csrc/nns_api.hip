@@ -155,7 +155,7 @@ static int prep_refs(nns_index *ix, hipStream_t st)
     const FilterGeom &g = ix->geom;
     NNS_HIP(hipMemsetAsync(ix->scal, 0, sizeof(DevScalars), st));
     if (ix->bf16) {
-        NNS_TRY(launch_prep_image_bf16((NNS_BF16_TILE16 && g.kt <= 512) ? 1 : 0, g.kt, ix->k, ix->n, g.n_pad, (const uint16_t *)ix->r_dev, -2.0f, INFINITY,
+        NNS_TRY(launch_prep_image_bf16(g.lpq == 4 ? 1 : 0, g.kt, ix->k, ix->n, g.n_pad, (const uint16_t *)ix->r_dev, -2.0f, INFINITY,
                                        ix->rimg, ix->rnorm, &ix->scal->ymax2_bits,
                                        &ix->scal->r_maxabs_bits, st));
         return NNS_OK;
@@ -507,7 +507,7 @@ static int index_search_impl(nns_index *ix, int m, const void *q_dev, int bf16, 
                   "per-search scalars must be adjacent");
     NNS_HIP(hipMemsetAsync(&ix->scal->q_maxabs_bits, 0, sizeof(unsigned) + 2 * sizeof(int), st));
     if (bf16)
-        NNS_TRY(launch_prep_image_bf16((NNS_BF16_TILE16 && g.kt <= 512) ? 1 : 0, g.kt, ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
+        NNS_TRY(launch_prep_image_bf16(g.lpq == 4 ? 1 : 0, g.kt, ix->k, m, g.m_pad, (const uint16_t *)q_dev, 1.0f, 0.0f, ix->qimg, ix->qnorm,
                                        nullptr, &ix->scal->q_maxabs_bits, st));
     else
         NNS_TRY(launch_prep_image(ix->k, g.kt, m, g.m_pad, (const float *)q_dev, ix->mean, 1.0f, 0.0f,
@@ -1136,10 +1136,11 @@ int nns_warmup(int device)
     NNS_TRY(ensure_device_ok(device));
     // (k, m, n, bf16, path): K1a (3-D and 16-D), K1b, the fp32 tile depths 16 / 32 / 64 / 128 / 256 (forced onto the
     // filter: AUTO keeps a 64 x 512 x 16 problem on the exact kernel), the bf16-operand tiles for fp32 points (512 /
-    // 640 / 768 / 1024: AUTO), the bf16 tiles 128 / 256 / 512 / 640 / 768 / 1024
+    // 384 / 512 / 640 / 768 / 1024: AUTO), the bf16 tiles 128 / 256 / 384 / 512 / 640 / 768 / 1024
     static const int shapes[][5] = {{3, 64, 512, 0, NNS_PATH_AUTO},    {16, 64, 512, 0, NNS_PATH_AUTO},  {16, 1, 512, 0, NNS_PATH_AUTO},
                                     {16, 64, 512, 0, NNS_PATH_MFMA},   {24, 64, 512, 0, NNS_PATH_MFMA},  {40, 64, 512, 0, NNS_PATH_MFMA},
                                     {100, 64, 512, 0, NNS_PATH_MFMA},  {200, 64, 512, 0, NNS_PATH_MFMA}, {300, 64, 512, 0, NNS_PATH_AUTO},
+                                    {400, 64, 512, 0, NNS_PATH_AUTO},  {400, 64, 512, 1, NNS_PATH_MFMA},
                                     {600, 64, 512, 0, NNS_PATH_AUTO},  {700, 64, 512, 0, NNS_PATH_AUTO}, {800, 64, 512, 0, NNS_PATH_AUTO},
                                     {64, 64, 512, 1, NNS_PATH_MFMA},   {200, 64, 512, 1, NNS_PATH_MFMA}, {300, 64, 512, 1, NNS_PATH_MFMA},
                                     {600, 64, 512, 1, NNS_PATH_MFMA},  {700, 64, 512, 1, NNS_PATH_MFMA}, {800, 64, 512, 1, NNS_PATH_MFMA}};

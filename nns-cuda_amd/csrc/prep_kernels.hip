@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void image_mixed512_kernel(int order, int k, i
 // fixed order).  T = float: centred by the mean, ONE rounding to bf16 (NNS_FILTER_BF16 / AUTO for fp32 points
 // beyond the fp32 tiles); T = uint16_t: bf16 bit patterns, no centring (a centred bf16 value would need a
 // second rounding).  Same values as image_mixed512_kernel / image_bf16_kernel would produce at their depths.
-// (KT = 768: three parts of 256 dims; KT = 640: five parts of 128.)
+// (KT = 768: three parts of 256 dims; KT = 640 / 384: five / three parts of 128.)
 template <int KT, typename T, int HD = 512>
 __global__ __launch_bounds__(256) void image_deep_kernel(int k, int npts, const T *__restrict__ pts,
                                                          const float *__restrict__ mean, float scale, float pad_norm,
@@ -439,11 +439,14 @@ int launch_prep_image(int k, int kt, int npts, int npts_pad, const float *pts, c
 {
     const int blocks = npts_pad / 32;
     if (out_bf16) {
-        if (kt != 1024 && kt != 768 && kt != 640 && kt != 512 && kt != 256 && kt != 128) {
-            set_error("prep: the bf16 operand image is 128, 256, 512, 640, 768 or 1024 deep (kt = %d)", kt);
+        if (kt != 1024 && kt != 768 && kt != 640 && kt != 512 && kt != 384 && kt != 256 && kt != 128) {
+            set_error("prep: the bf16 operand image is 128, 256, 384, 512, 640, 768 or 1024 deep (kt = %d)", kt);
             return NNS_ERR_UNSUPPORTED;
         }
-        if (kt == 640)
+        if (kt == 384)
+            hipLaunchKernelGGL((image_deep_kernel<384, float, 128>), dim3(blocks), dim3(256), 0, st, k, npts, pts, mean, scale,
+                               pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
+        else if (kt == 640)
             hipLaunchKernelGGL((image_deep_kernel<640, float, 128>), dim3(blocks), dim3(256), 0, st, k, npts, pts, mean, scale,
                                pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
         else if (kt == 768)
@@ -615,6 +618,9 @@ int launch_prep_image_bf16(int order, int kt, int k, int npts, int npts_pad, con
                            pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
     else if (kt == 1024 && order == 0)
         hipLaunchKernelGGL((image_deep_kernel<1024, uint16_t>), dim3(npts_pad / 32), dim3(256), 0, st, k, npts, pts,
+                           (const float *)nullptr, scale, pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
+    else if (kt == 384 && order == 0)
+        hipLaunchKernelGGL((image_deep_kernel<384, uint16_t, 128>), dim3(npts_pad / 32), dim3(256), 0, st, k, npts, pts,
                            (const float *)nullptr, scale, pad_norm, (uint16_t *)img, norms, max_norm_bits, maxabs_bits);
     else if (kt == 640 && order == 0)
         hipLaunchKernelGGL((image_deep_kernel<640, uint16_t, 128>), dim3(npts_pad / 32), dim3(256), 0, st, k, npts, pts,

@@ -86,7 +86,7 @@ def _bf16_model_cases(rng, kt):
 
 
 @pytest.mark.parametrize("shape", [2, 1])
-@pytest.mark.parametrize("kt", [128, 256, 512, 640, 768, 1024])
+@pytest.mark.parametrize("kt", [128, 256, 384, 512, 640, 768, 1024])
 def test_bf16_mfma_error_model(pkg, orc, shape, kt):
     """The bf16 MFMA's accumulation (fp32 accumulate, order and rounding undocumented) against fp64 on
     bf16-representable operands, at EVERY depth the product runs bf16 tiles (128 / 256 / 512 / 1024), for both
@@ -121,7 +121,7 @@ def test_bf16_mfma_error_model(pkg, orc, shape, kt):
     print(f"bf16 MFMA shape {shape} kt {kt}: worst error / e3 bound = {worst:.4f}")
 
 
-@pytest.mark.parametrize("kt", [128, 256, 512, 640, 768, 1024])
+@pytest.mark.parametrize("kt", [128, 256, 384, 512, 640, 768, 1024])
 def test_bf16_operand_rounding_model_mode2(pkg, orc, kt):
     """tau mode 2 (fp32 points, operands rounded to bf16, NNS_FILTER_BF16): the filter's score error
     against the UNROUNDED fp32 values — rounding bound 2^-6 (1 + 2^-8) |x'||y'| plus the accumulate
@@ -840,10 +840,12 @@ def test_filter_k64_tile_shapes(pkg, orc, shape):
     ix.close()
 
 
-@pytest.mark.parametrize("shape", [(300, 5000, 512), (700, 20001, 300), (130, 3000, 400), (2049, 777, 257)])
+@pytest.mark.parametrize("shape", [(300, 5000, 512), (700, 20001, 300), (130, 3000, 400), (2049, 777, 257), (513, 33000, 384),
+                                   (300, 5000, 385)])
 def test_bf16_k512_tile_shapes(pkg, orc, shape):
-    """bf16 points with 256 < k <= 512: the 512-deep tile (v_mfma_f32_32x32x16_bf16, one query block per
-    wave, one 32-ref block per ring slot), forced and under AUTO, whole and sharded."""
+    """bf16 points with 256 < k <= 512: the 512-deep tile (16x16x32 MFMAs, four waves) and, up to k = 384, the
+    384-deep one (24 fragment steps per block: four blocks over three ring slots, eight waves), forced and under AUTO,
+    whole and sharded."""
     m, n, k = shape
     rng = np.random.default_rng(5120 + k)
     q = rng.random((m, k), dtype=np.float32)
@@ -853,11 +855,11 @@ def test_bf16_k512_tile_shapes(pkg, orc, shape):
     ix = pkg.Index(torch.from_numpy(orc.round_bf16(r)).cuda().to(torch.bfloat16))
     ix.search(torch.from_numpy(orc.round_bf16(q)).cuda().to(torch.bfloat16))
     st = ix.stats()
-    assert st["path"] == 2 and st["k_tile"] == 512, st
+    assert st["path"] == 2 and st["k_tile"] == (384 if k <= 384 else 512), st   # (256 < k <= 384: the 384-deep tile, round 3)
     ix.close()
 
 
-@pytest.mark.parametrize("shape", [(300, 5000, 512), (700, 20001, 300), (130, 3000, 400), (1100, 9000, 257)])
+@pytest.mark.parametrize("shape", [(300, 5000, 512), (700, 20001, 300), (130, 3000, 400), (1100, 9000, 257), (513, 33000, 384), (300, 5000, 385)])
 def test_fp32_points_k512_bf16_operand_tile(pkg, orc, shape):
     """fp32 points with 256 < k <= 512: no fp32 tile is that deep, so AUTO runs the bf16-operand filter
     (512-deep tile, rounding-widened margin) + the exact fp32 re-rank.  V0's bits, whole and sharded,
@@ -880,7 +882,7 @@ def test_fp32_points_k512_bf16_operand_tile(pkg, orc, shape):
     ix = pkg.Index(torch.from_numpy(r).cuda())
     ix.search(torch.from_numpy(q).cuda())
     st = ix.stats()
-    assert st["path"] == 2 and st["k_tile"] == 512, st
+    assert st["path"] == 2 and st["k_tile"] == (384 if k <= 384 else 512), st   # (256 < k <= 384: the 384-deep tile, round 3)
     ix.close()
 
 

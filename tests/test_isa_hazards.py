@@ -53,7 +53,7 @@ def test_filter_kernels_have_no_mfma_read_hazards():
                 cur = None
                 continue
             cur.append((i, l))
-    assert len(kernels) == 11, list(kernels)   # fp32 KT = 16 / 32 / 64 / 128 / 256, bf16 KT = 128 / 256 / 512 / 640 / 768 / 1024
+    assert len(kernels) == 12, list(kernels)   # fp32 KT = 16 / 32 / 64 / 128 / 256, bf16 KT = 128 / 256 / 384 / 512 / 640 / 768 / 1024
     for name, lines in kernels.items():
         assert sum("v_mfma" in l for _, l in lines) >= 64, name   # (every interval is fully unrolled: 32 steps)
         assert chk.check_kernel(name, lines) == [], name

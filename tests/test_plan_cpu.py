@@ -14,6 +14,8 @@ def _check_plan(p, k, m, n):
         assert p["n_pad"] % 64 == 0 and p["total_slots"] * 64 == p["n_pad"] * 3 and p["slots_per_split"] % 3 == 0
     elif p["kt"] == 640:    # four 40-step blocks (128 refs) per five ring slots
         assert p["n_pad"] % 128 == 0 and p["total_slots"] * 128 == p["n_pad"] * 5 and p["slots_per_split"] % 5 == 0
+    elif p["kt"] == 384:    # four 24-step blocks (128 refs) per three ring slots
+        assert p["n_pad"] % 128 == 0 and p["total_slots"] * 128 == p["n_pad"] * 3 and p["slots_per_split"] % 3 == 0
     else:
         assert p["n_pad"] == p["total_slots"] * p["slot_pts"]
     # splits x slots_per_split covers every slot, the last split is not empty
@@ -22,6 +24,7 @@ def _check_plan(p, k, m, n):
     assert p["splits"] <= 65535
     # record form: per (lane, ref tile) only on short streams, and only with K5's one-wave-per-query form
     tiles_per_stream = (p["slots_per_split"] * 2 // 3 if p["kt"] == 768 else p["slots_per_split"] * 4 // 5 if p["kt"] == 640 else
+                        p["slots_per_split"] * 4 // 3 if p["kt"] == 384 else
                         p["slots_per_split"] * max(p["slot_pts"], 32) // 32 // (2 if p["kt"] == 1024 else 1))
     if p["tile_rec"]:
         assert p["splits"] >= 4 and tiles_per_stream <= 2048 and p["share_thr"] == 1
@@ -36,10 +39,10 @@ def test_tile_depth_by_dimensionality(pkg):
     for k, kt in want_f32.items():
         p = pkg.plan_filter(k, 1000, 50000)
         assert (p["kt"], p["bf16"], p["mixed"]) == (kt, 0, 0), (k, p)
-    for k, kt in {257: 512, 512: 512, 513: 640, 640: 640, 641: 768, 768: 768, 769: 1024, 1024: 1024}.items():      # fp32 points beyond the fp32 tiles
+    for k, kt in {257: 384, 384: 384, 385: 512, 512: 512, 513: 640, 640: 640, 641: 768, 768: 768, 769: 1024, 1024: 1024}.items():      # fp32 points beyond the fp32 tiles
         p = pkg.plan_filter(k, 1000, 50000)
         assert (p["kt"], p["bf16"], p["mixed"]) == (kt, 1, 1), (k, p)
-    for k, kt in {32: 128, 128: 128, 129: 256, 256: 256, 257: 512, 512: 512, 600: 640, 640: 640, 700: 768, 768: 768, 769: 1024, 1024: 1024}.items():
+    for k, kt in {32: 128, 128: 128, 129: 256, 256: 256, 257: 384, 384: 384, 385: 512, 512: 512, 600: 640, 640: 640, 700: 768, 768: 768, 769: 1024, 1024: 1024}.items():
         p = pkg.plan_filter(k, 1000, 50000, bf16=True)
         assert (p["kt"], p["bf16"], p["mixed"]) == (kt, 1, 0), (k, p)
     assert pkg.plan_filter(100, 1000, 50000, flags=pkg.NNS_FILTER_BF16)["mixed"] == 1

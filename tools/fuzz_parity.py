@@ -60,7 +60,7 @@ def main():
     cases = fails = 0
     last = t0
     while time.time() - t0 < a.seconds:
-        k = int(rng.choice([1, 2, 3, 4, 7, 8, 15, 16, 17, 31, 32, 33, 64, 65, 100, 128, 129, 200, 256, 257, 300, 400, 512, 513, 600, 640, 641, 700,
+        k = int(rng.choice([1, 2, 3, 4, 7, 8, 15, 16, 17, 31, 32, 33, 64, 65, 100, 128, 129, 200, 256, 257, 300, 384, 385, 400, 512, 513, 600, 640, 641, 700,
                             768, 769, 777, 1024, 1025]))
         m = int(rng.choice([1, 2, 3, 4, 5, 31, 63, 64, 65, 255, 512, 513, 1000, 2049]))
         n = int(rng.choice([1, 5, 31, 64, 65, 257, 1000, 4097, 20001, 70000, 150000]))

@@ -17,7 +17,7 @@ if "--k16" in sys.argv:     # the shallow fp32 tiles only
 if "--nw4" in sys.argv:     # the one-wave-per-SIMD tiles only
     CASES = [(512, "bf16"), (1024, "bf16")]
 if "--k512" in sys.argv:
-    CASES = [(512, "bf16"), (512, "f32"), (300, "bf16")]
+    CASES = [(512, "bf16"), (512, "f32"), (300, "bf16"), (384, "bf16"), (300, "f32")]
 for k, dt in CASES:
     q = torch.empty((m, k), dtype=torch.float32, device="cuda"); r = torch.empty((n, k), dtype=torch.float32, device="cuda")
     pkg.fill_uniform(q, 1000, 0); pkg.fill_uniform(r, 1000, m * k)
