@@ -1075,6 +1075,14 @@ def test_bench_self_launch_rehearsal():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["verified_vs_unsharded"] is True
     assert d["exchange"]["matches_torch_all_reduce"] is True and d["exchange"]["queries_won_sum_over_ranks"] >= d["config"]["m"]
+    # round 3: the line says where a step's time went on every rank, and every cross-check is enforced
+    rk = d["ranks"]
+    for f in ("step_ms", "search_ms", "exchange_ms"):
+        assert len(rk[f]) == 2 and all(v > 0 for v in rk[f]), rk
+    assert rk["step_ms_max"] == max(rk["step_ms"]) and rk["slowest_rank"] in (0, 1)
+    assert max(rk["step_ms"]) <= d["ms_per_step"] * 1.05          # a rank's own time fits the max-over-ranks step
+    assert all(s_ + e_ <= t * 1.05 for s_, e_, t in zip(rk["search_ms"], rk["exchange_ms"], rk["step_ms"]))
+    assert d["exchange"]["exchange_ms"]["payload_bytes"] == 8 * d["config"]["m"] and d["parity_ok"] is True
 
 
 def test_search_indices_fused_unpack_and_k1a_rearm(pkg, orc):
