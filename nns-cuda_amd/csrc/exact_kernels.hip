@@ -548,6 +548,38 @@ static size_t k1a_workspace_keys(int m, int n)
     return (size_t)m + ((size_t)p.qtiles * sizeof(int) + 7) / 8 + 1;
 }
 
+// K1f (below): the filter + exact re-rank form of this search for k <= 3
+#ifndef NNS_K1F_CH
+#define NNS_K1F_CH 16
+#endif
+#ifndef NNS_K1F_QPL
+#define NNS_K1F_QPL 2
+#endif
+constexpr int K1F_CH = NNS_K1F_CH;      // refs per chunk (16 or 32)
+constexpr int K1F_QPL = NNS_K1F_QPL;    // queries per lane
+constexpr int K1F_TILE = 1024;  // refs per LDS tile: 16 KiB of float4
+template <int K>
+__global__ void lowdim_filter_kernel(int m, int n, int refs_per_split, const float *__restrict__ q, const float *__restrict__ r,
+                                     int64_t index_base, nns_key *__restrict__ keys, const K1aMerge mg);
+#ifndef NNS_K1F_MIN_PAIRS
+#define NNS_K1F_MIN_PAIRS ((int64_t)1 << 24)
+#endif
+#ifndef NNS_K1F_MIN_PER
+#define NNS_K1F_MIN_PER 512
+#endif
+#ifndef NNS_K1F_WAVES
+#define NNS_K1F_WAVES 4096   // target number of waves in a K1f grid (4 per SIMD)
+#endif
+template <int K>
+static bool k1f_wanted(int m, int n, const K1aPlan &p)
+{
+#ifdef NNS_K1F_OFF   // (A/B builds)
+    return false;
+#else
+    return K <= 3 && p.nw == 8 && p.per >= NNS_K1F_MIN_PER && (int64_t)m * n >= NNS_K1F_MIN_PAIRS;
+#endif
+}
+
 template <int K>
 static int launch_k1a(int m, int n, const float *q, const float *r, int64_t base,
                       nns_key *keys, nns_key *ws, size_t ws_keys, bool ws_fresh, int *idx_out, float *dist_out,
@@ -573,6 +605,30 @@ static int launch_k1a(int m, int n, const float *q, const float *r, int64_t base
         }
     }
     mg.splits = p.splits;
+    // k <= 3, eight-wave workgroups with at least a few chunks per wave, enough pairs to pay for the re-rank stage:
+    // the filter + exact re-rank form (K1f).  Same grid, same merge workspace; ranges are whole 16-ref chunks.
+    bool use_f = false;
+    int per_f = 0;
+    if constexpr (K <= 3) {
+        if (k1f_wanted<K>(m, n, p)) {
+            // ~110 registers at k = 3: four waves per SIMD, two workgroups per CU — cut for ONE round of them; a
+            // workgroup holds 64 x K1F_QPL queries (the counters of the merge workspace are per 128 queries: enough)
+            const int qtf = divup(m, 64 * K1F_QPL);
+            int want = divup(NNS_K1F_WAVES, qtf * 8);
+            const int maxs = divup(n, NNS_K1F_MIN_PER);
+            if (want > maxs) want = maxs;
+            if (want < 1) want = 1;
+            const int per = divup(divup(n, want), K1F_CH) * K1F_CH;
+            const int splits = divup(n, per);
+            if (splits <= 1 || mg.acc) {   // (the merge workspace does not depend on the cut)
+                use_f = true;
+                per_f = per;
+                p.qtiles = qtf;
+                p.splits = splits;
+                mg.splits = splits;
+            }
+        }
+    }
 #ifdef NNS_K1A_STAMPS
     static unsigned long long *stamps_dev = nullptr;
     const size_t nwg = (size_t)p.qtiles * p.splits;
@@ -581,7 +637,10 @@ static int launch_k1a(int m, int n, const float *q, const float *r, int64_t base
     mg.stamps = stamp ? stamps_dev : nullptr;
     if (stamp) NNS_HIP(hipMemsetAsync(stamps_dev, 0, nwg * 64 * sizeof(unsigned long long), st));
 #endif
-    if (p.nw <= 8)
+    if (use_f) {
+        if constexpr (K <= 3)
+            hipLaunchKernelGGL((lowdim_filter_kernel<K>), dim3(p.qtiles, p.splits), dim3(512), 0, st, m, n, per_f, q, r, base, keys, mg);
+    } else if (p.nw <= 8)
         hipLaunchKernelGGL((exact_lane_query_kernel<K, 8>), dim3(p.qtiles, p.splits), dim3(64 * p.nw), 0, st,
                            m, n, p.per, q, r, base, keys, mg);
     else
@@ -606,6 +665,426 @@ static int launch_k1a(int m, int n, const float *q, const float *r, int64_t base
     }
 #endif
     return NNS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// K1f: K1a's geometry as FILTER + EXACT RE-RANK on the vector ALU (k <= 3)
+// ---------------------------------------------------------------------------
+// V0's sub / mul / add cannot fuse, so the exact kernel above pays 3k - 1 = 8 instructions per pair at
+// k = 3 — 0.60 of the non-FMA vector rate is where it sits at C2.  But only the WINNER needs V0's arithmetic.  With
+// x' = q - c, y' = r - c (c = the first ref of the workgroup's range: clouds far from the origin keep their
+// resolution), the score  s(i, j) = |y'_j|^2 - 2 x'_i . y'_j  has the same argmin over j as the squared distance and is
+// K FMAs per pair on operands prepared once per ref: the workgroup stages its tiles as (y'_0, y'_1, y'_2, |y'|^2) — one
+// broadcast ds_read_b128 per ref — and a lane walks them for its two queries with 3 v_fma per pair.  Record
+// collection is the filter's branch-free form 2 (filter_mfma.hip): per CHUNK of 16 refs the minimum of the lane's 16
+// scores (v_min3 tree) is inserted into the lane's sorted best three chunk minima (v_med3), the chunks of the best two
+// remembered: 4.1 vector instructions per pair instead of 9.1.  At the end of the range the workgroup merges its waves'
+// entries per query (LDS), takes a = the smallest chunk minimum, and — tau(a) bounding |s + |x'|^2 - V0's distance| from
+// both sides exactly as for the MFMA filter (finalize.hip; here an FMA chain of K steps behind an FMA-evaluated norm:
+// tau_consts' fp32 model with kt = 8 covers it) —
+//   * evaluates V0's own arithmetic on the 2 x 16 refs of the best two chunks, 16 lanes side by side, reading the
+//     ORIGINAL coordinates: the (distance, index)-lexicographic minimum is V0's answer for this range, ties included,
+//     because every ref whose score is within tau(a) of a lies in one of those chunks —
+//   * unless the THIRD-best chunk minimum is within tau(a) too (three chunks within the filter's resolution: duplicates,
+//     lattices): then the whole workgroup scans the range for that query with V0's arithmetic (lane = ref), and if more
+//     than a few queries need it, or a ref is NaN / INF / huge (a score could overflow), every lane walks the range for
+//     its own queries exactly as K1a does.  Slower on such inputs, never different.
+// The cross-split stage is K1a's (returning atomic mins on exact keys, last workgroup writes), minus the index recovery.
+#ifndef NNS_K1F_MAX_AMB
+#define NNS_K1F_MAX_AMB 8       // ambiguous queries a workgroup scans one by one before it falls back as a whole
+#endif
+
+// minimum of a packed key over the 16 lanes of each DPP row, on every lane of the row (row rotations: no LDS round trip)
+template <int CTRL>
+__device__ __forceinline__ nns_key key_min_dpp(nns_key v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, false);
+    const nns_key o = ((nns_key)(uint32_t)hi << 32) | (uint32_t)lo;
+    return o < v ? o : v;
+}
+__device__ __forceinline__ nns_key row_min_key(nns_key v)
+{
+    v = key_min_dpp<0x128>(v);   // row_ror:8
+    v = key_min_dpp<0x124>(v);   // row_ror:4
+    v = key_min_dpp<0x122>(v);   // row_ror:2
+    return key_min_dpp<0x121>(v);   // row_ror:1
+}
+
+// tau(a) of the VALU filter in fp32, rounded up everywhere: tau_consts(kt = 8, mode 0) with (X + Y)^2 <= 2 (X^2 + Y^2):
+// c0 <= 62.2 u (X^2 + Y^2), c1 <= 20.1 u
+__device__ __forceinline__ float k1f_tau(float a, float x2, float y2)
+{
+    const float d = a + x2;
+    return 3.8185e-6f * (x2 + y2) + 1.9074e-6f * (d > 0.0f ? d : 0.0f);   // 2^-18 x 1.001, 2^-19
+}
+
+template <int K>
+__global__ __launch_bounds__(512) void lowdim_filter_kernel(
+    int m, int n, int refs_per_split, const float *__restrict__ q,
+    const float *__restrict__ r, int64_t index_base, nns_key *__restrict__ keys, const K1aMerge mg)
+{
+    static_assert(K >= 1 && K <= 3, "a ref is one float4: up to three centred coordinates + the norm");
+    constexpr int CH = K1F_CH, TILE = K1F_TILE;
+    constexpr int QPL = K1F_QPL, QW = 64 * QPL;
+    static_assert(CH == 16 || CH == 32, "the re-rank stage evaluates a chunk with 16 or 32 lanes");
+    constexpr int MAXNW = 8, nthreads = 512, nw = 8;   // always eight waves (launch_k1a sends smaller problems to K1a)
+    constexpr int SREF_N = 2 * TILE > 5 * MAXNW * QW / 4 ? 2 * TILE : 5 * MAXNW * QW / 4;
+    __shared__ __attribute__((aligned(16))) float4 sref[SREF_N];          // two tile buffers; the merge entries afterwards
+    __shared__ __attribute__((aligned(16))) float sq[QW * K];              // the workgroup's queries, original coordinates
+    __shared__ float s_ymax[MAXNW];
+    __shared__ nns_key s_fkey[QW];      // the workgroup's exact key per query
+    __shared__ int s_cand[QW][2];       // the two chunks to evaluate
+    __shared__ int s_amb[QW];           // ambiguous queries (list)
+    __shared__ int s_namb, s_bad, s_last;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j0 = blockIdx.y * refs_per_split;   // (< n)
+    const int64_t j1l = (int64_t)j0 + refs_per_split;
+    const int j1 = j1l > n ? n : (int)j1l;
+    if (threadIdx.x == 0) {
+        s_namb = 0;
+        s_bad = 0;
+    }
+    // the centre: the range's first ref (wave-uniform loads)
+    float cen[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) cen[t] = r[(size_t)j0 * K + t];
+
+    // queries -> LDS by LDS-DMA (as K1a): 16-byte pieces where source and count allow, dword pieces otherwise
+    {
+        const int64_t qbase = (int64_t)blockIdx.x * QW * K, qleft = (int64_t)m * K - qbase;
+        const float *src = q + qbase;
+        const int nvalid = qleft < QW * K ? (int)qleft : QW * K;
+        const unsigned dst_lds = (unsigned)(uintptr_t)sq;
+        const int n4 = (((uintptr_t)src & 15) == 0) ? (nvalid & ~3) : 0;
+        for (int e0 = wave * 256; e0 < n4; e0 += nthreads * 4) {
+            const int e = e0 + lane * 4;
+            if (e < n4) dma16(src + e, dst_lds + (unsigned)e0 * 4u);
+        }
+        for (int e0 = n4 + wave * 64; e0 < QW * K; e0 += nthreads) {
+            const int e = e0 + lane;
+            if (e < nvalid) dma4(src + e, dst_lds + (unsigned)e0 * 4u);
+            else if (e < QW * K) sq[e] = 0.0f;
+        }
+    }
+    // ---- staging: refs t0 .. t0 + TILE of the range -> (y', |y'|^2) in tile buffer buf -------------------------
+    // The loads are issued BEFORE the walk of the current tile (stage_load: K dwords per ref, lane = ref: 12-byte
+    // stride, every byte of the lines used), the arithmetic and the LDS stores follow it (stage_store): two refs per
+    // lane and tile, 2 K registers across the walk.
+    constexpr int SPT = TILE / nthreads;
+    float sv[SPT][K];
+    float ymax = 0.0f;
+    bool bad = false;
+    auto stage_load = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int j = t0 + i * nthreads + (int)threadIdx.x;
+#pragma unroll
+            for (int t = 0; t < K; ++t) sv[i][t] = j < j1 ? r[(size_t)j * K + t] : 0.0f;
+        }
+    };
+    auto stage_store = [&](int t0, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int e = i * nthreads + (int)threadIdx.x;
+            float4 o = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());   // padding: score +INF, never a minimum
+            if (t0 + e < j1) {
+                float yc[3] = {0.0f, 0.0f, 0.0f};
+                float nrm = 0.0f;
+#pragma unroll
+                for (int t = 0; t < K; ++t) {
+                    const float v = sv[i][t];
+                    bad = bad || !(fabsf(v) < 1e17f);          // NaN, INF, or a square that could overflow
+                    yc[t] = __fsub_rn(v, cen[t]);
+                    nrm = __builtin_fmaf(yc[t], yc[t], nrm);
+                }
+                ymax = fmaxf(ymax, nrm);
+                o = make_float4(yc[0], yc[1], yc[2], nrm);
+            }
+            sref[buf * TILE + e] = o;
+        }
+    };
+
+    K1A_STAMP(0);
+    stage_load(j0);
+    stage_store(j0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of the queries have landed
+    __syncthreads();
+    K1A_STAMP(1);
+    // lane state: -2 x' of its two queries; best three chunk minima, the chunks of the best two
+    float x2[QPL][K], xn[QPL];
+    float m1[QPL], m2[QPL], m3[QPL];
+    int c1[QPL], c2[QPL];
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) {
+        xn[u] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const float xc = __fsub_rn(sq[(u * 64 + lane) * K + t], cen[t]);
+            xn[u] = __builtin_fmaf(xc, xc, xn[u]);
+            x2[u][t] = -2.0f * xc;
+        }
+        m1[u] = m2[u] = m3[u] = __builtin_inff();
+        c1[u] = c2[u] = j0;
+    }
+    int buf = 0;
+    for (int t0 = j0; t0 < j1; t0 += TILE, buf ^= 1) {
+        const int cnt = (j1 - t0) < TILE ? (j1 - t0) : TILE;
+        const bool more = t0 + TILE < j1;
+        if (more) stage_load(t0 + TILE);
+        const float4 *tile = sref + buf * TILE;
+#if defined(NNS_DIAG) && defined(NNS_K1F_ABLATE) && (NNS_K1F_ABLATE & 1)   // timing experiment: no walk (results are wrong)
+        if (m < 0)
+#endif
+        for (int c = wave * CH; c < cnt; c += nw * CH) {
+            // the chunk in pieces of 8 refs (32-ref chunks: a ROLLED loop — unrolled, hipcc walks a query over the whole
+            // chunk at a time and keeps all its refs in registers, 128 of them: one workgroup per CU)
+            float tmq[QPL];
+#pragma unroll
+            for (int u = 0; u < QPL; ++u) tmq[u] = __builtin_inff();
+#pragma unroll(CH <= 16 ? 2 : 1)
+            for (int piece = 0; piece < CH / 8; ++piece) {
+                float4 rf[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rf[e] = tile[c + 8 * piece + e];   // uniform address: broadcast reads
+#pragma unroll
+                for (int u = 0; u < QPL; ++u) {
+                    float sc[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float a = rf[e].w;
+                        a = __builtin_fmaf(x2[u][0], rf[e].x, a);
+                        if constexpr (K > 1) a = __builtin_fmaf(x2[u][1], rf[e].y, a);
+                        if constexpr (K > 2) a = __builtin_fmaf(x2[u][2], rf[e].z, a);
+                        sc[e] = a;
+                    }
+                    const float g0 = fminf(fminf(sc[0], sc[1]), sc[2]), g1 = fminf(fminf(sc[3], sc[4]), sc[5]);
+                    tmq[u] = fminf(fminf(fminf(g0, g1), fminf(sc[6], sc[7])), tmq[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < QPL; ++u) {
+                const float tm = tmq[u];
+                // sorted insert (the filter's record form 2): strict compares, equal minima fill the next rank
+                const float o1 = m1[u], o2 = m2[u];
+                const bool lt1 = tm < o1, lt2 = tm < o2;
+                m3[u] = __builtin_amdgcn_fmed3f(tm, o2, m3[u]);
+                m2[u] = __builtin_amdgcn_fmed3f(tm, o1, o2);
+                m1[u] = fminf(o1, tm);
+                c2[u] = lt1 ? c1[u] : (lt2 ? t0 + c : c2[u]);
+                c1[u] = lt1 ? t0 + c : c1[u];
+            }
+        }
+        if (more) {
+            stage_store(t0 + TILE, buf ^ 1);   // (that buffer's tile was finished before the last barrier)
+            __syncthreads();
+            K1A_STAMP(2 + ((t0 - j0) / TILE < 4 ? (t0 - j0) / TILE : 4));
+        }
+    }
+    K1A_STAMP(7);
+    // ---- the workgroup's waves: entries through LDS (the tile buffers are idle now) ---------------------------------
+    {   // non-finite / huge refs anywhere in the range, and the largest norm
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+        if (lane == 0) s_ymax[wave] = ymax;
+        if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) s_bad = 1;
+    }
+    __syncthreads();
+    float *em1 = reinterpret_cast<float *>(sref);            // [nw][QW] each
+    float *em2 = em1 + MAXNW * QW, *em3 = em2 + MAXNW * QW;
+    int *ec1 = reinterpret_cast<int *>(em3 + MAXNW * QW), *ec2 = ec1 + MAXNW * QW;
+    static_assert(sizeof(sref) >= 5 * 4 * MAXNW * QW, "merge entries fit the tile buffers");
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) {
+        const int e = wave * QW + u * 64 + lane;
+        em1[e] = m1[u];
+        em2[e] = m2[u];
+        em3[e] = m3[u];
+        ec1[e] = c1[u];
+        ec2[e] = c2[u];
+    }
+    __syncthreads();
+    float y2 = 0.0f;
+    for (int w = 0; w < nw; ++w) y2 = fmaxf(y2, s_ymax[w]);
+    const bool wg_bad = s_bad != 0;
+    // wave w finishes the queries of register slots u = w, w + nw, ... (its lanes hold their |x'|^2)
+#pragma unroll
+    for (int u = 0; u < QPL; ++u)
+        if (u % nw == wave) {   // (wave-uniform)
+            const int ql = u * 64 + lane;
+            float a1 = __builtin_inff(), a2 = a1, a3 = a1;
+            int b1 = j0, b2 = j0;
+            auto insert = [&](float tm, int ch) __attribute__((always_inline)) {
+                const float o1 = a1, o2 = a2;
+                const bool lt1 = tm < o1 || (tm == o1 && ch < b1), lt2 = tm < o2 || (tm == o2 && ch < b2);   // (chunk order among equals)
+                a3 = __builtin_amdgcn_fmed3f(tm, o2, a3);
+                a2 = __builtin_amdgcn_fmed3f(tm, o1, o2);
+                a1 = fminf(o1, tm);
+                b2 = lt1 ? b1 : (lt2 ? ch : b2);
+                b1 = lt1 ? ch : b1;
+            };
+#pragma unroll
+            for (int w = 0; w < nw; ++w) {   // (unrolled: all 5 nw entries are read before the dependent inserts)
+                const int e = w * QW + ql;
+                insert(em1[e], ec1[e]);
+                insert(em2[e], ec2[e]);
+                a3 = fminf(a3, em3[e]);   // (a third minimum has no chunk: it only ever decides "ambiguous")
+            }
+            const float thr = a1 + k1f_tau(a1, xn[u] * 1.00001f, y2 * 1.00001f);
+            s_cand[ql][0] = b1;
+            s_cand[ql][1] = b2;
+            s_fkey[ql] = NNS_KEY_NONE;
+            // three chunks within the filter's resolution (or a threshold that is not a number): scan the range
+            if (!wg_bad && !(a3 > thr) && blockIdx.x * QW + ql < m) s_amb[atomicAdd(&s_namb, 1)] = ql;
+        }
+    __syncthreads();
+    K1A_STAMP(8);
+    const int namb = s_namb;
+    const bool whole = wg_bad || namb > NNS_K1F_MAX_AMB;   // (workgroup-uniform)
+#if defined(NNS_DIAG) && defined(NNS_K1F_ABLATE) && (NNS_K1F_ABLATE & 2)   // timing experiment: no re-rank (results are wrong)
+    if (m < 0)
+#endif
+    if (!whole) {
+        // ---- V0 on the refs of the two best chunks of every query: 16 lanes per chunk, 2 queries per wave pass ------
+        // (CH = 16: 2 queries per wave pass, 16 lanes per chunk; CH = 32: 1 query per pass, 32 lanes per chunk)
+        constexpr int QPP = 64 / (2 * CH);   // queries per wave pass
+        constexpr int NPASS = QW / QPP / nw;  // passes per wave
+        static_assert(QW % (QPP * nw) == 0, "whole passes");
+        // every pass's coordinates are loaded first (one memory latency for all of them), then evaluated
+        float rr[NPASS][K];
+        int jj[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int it = wave + ps * nw;
+            const int ql = QPP * it + (lane / (2 * CH)), slot = (lane / CH) & 1;
+            const int j = s_cand[ql][slot] + (lane & (CH - 1));
+            const bool dup = slot == 1 && s_cand[ql][1] == s_cand[ql][0];   // (fewer than two chunks seen)
+            jj[ps] = (j < j1 && !dup) ? j : -1;
+#pragma unroll
+            for (int t = 0; t < K; ++t) rr[ps][t] = jj[ps] >= 0 ? r[(size_t)j * K + t] : 0.0f;
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int it = wave + ps * nw;
+            const int ql = QPP * it + (lane / (2 * CH));
+            nns_key key = NNS_KEY_NONE;
+            if (jj[ps] >= 0) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int t = 0; t < K; ++t) sum = v0_step(sum, sq[ql * K + t], rr[ps][t]);
+                key = make_key(sum, index_base + jj[ps]);
+            }
+            key = row_min_key(key);   // the 16 lanes of a row; then the rows of the query's two chunks
+#pragma unroll
+            for (int off = CH; off >= 16; off >>= 1) {
+                const uint32_t lo = __shfl_xor((uint32_t)key, off, 64), hi = __shfl_xor((uint32_t)(key >> 32), off, 64);
+                const nns_key o = ((nns_key)hi << 32) | lo;
+                key = o < key ? o : key;
+            }
+            if ((lane & (2 * CH - 1)) == 0) s_fkey[ql] = key;
+        }
+        __syncthreads();
+        // ---- ambiguous queries, one by one: the whole workgroup scans the range (lane = ref) ---------------------
+        for (int ai = 0; ai < namb; ++ai) {
+            const int ql = s_amb[ai];
+            float qr[K];
+#pragma unroll
+            for (int t = 0; t < K; ++t) qr[t] = sq[ql * K + t];
+            nns_key key = NNS_KEY_NONE;
+            for (int j = j0 + (int)threadIdx.x; j < j1; j += nthreads) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int t = 0; t < K; ++t) sum = v0_step(sum, qr[t], r[(size_t)j * K + t]);
+                const nns_key kj = make_key(sum, index_base + j);
+                key = kj < key ? kj : key;
+            }
+            key = wave_min_key(key);
+            if (lane == 0) atomicMin(reinterpret_cast<unsigned long long *>(&s_fkey[ql]), (unsigned long long)key);   // (LDS)
+        }
+        if (namb) __syncthreads();
+    } else {
+        // ---- the range as K1a walks it: every lane, its own queries, V0's arithmetic, refs by scalar loads --------
+        float best[QPL];
+        int bj[QPL];
+        float qv[QPL][K];
+#pragma unroll
+        for (int u = 0; u < QPL; ++u) {
+            best[u] = __builtin_inff();
+            bj[u] = j0;
+#pragma unroll
+            for (int t = 0; t < K; ++t) qv[u][t] = sq[(u * 64 + lane) * K + t];
+        }
+        for (int c = j0 + wave * 8; c < j1; c += nw * 8) {
+            float rv[8][K];
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+                const int j = __builtin_amdgcn_readfirstlane(c + cc < j1 ? c + cc : j1 - 1);   // wave-uniform, clamped
+#pragma unroll
+                for (int t = 0; t < K; ++t) rv[cc][t] = r[(size_t)j * K + t];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc)
+#pragma unroll
+                for (int u = 0; u < QPL; ++u) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < K; ++t) sum = v0_step(sum, qv[u][t], rv[cc][t]);
+                    const bool imp = sum < best[u] && c + cc < j1;   // strict, ascending j: the first minimum
+                    best[u] = imp ? sum : best[u];
+                    bj[u] = imp ? c + cc : bj[u];
+                }
+        }
+        nns_key(*wk)[QW] = reinterpret_cast<nns_key(*)[QW]>(sref);   // (the entries have been consumed: barrier above)
+#pragma unroll
+        for (int u = 0; u < QPL; ++u) wk[wave][u * 64 + lane] = make_key(best[u], index_base + bj[u]);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < QPL; ++u)
+            if (u % nw == wave) {
+                nns_key mine = NNS_KEY_NONE;
+                for (int w = 0; w < nw; ++w) {
+                    const nns_key o = wk[w][u * 64 + lane];
+                    mine = o < mine ? o : mine;
+                }
+                s_fkey[u * 64 + lane] = mine;
+            }
+        __syncthreads();
+    }
+    K1A_STAMP(9);
+    // ---- this range's exact keys: straight out, or through the cross-split stage (K1a's protocol) ---------------
+    auto put = [&](int qi, nns_key key) __attribute__((always_inline)) {
+        keys[qi] = key;
+        if (mg.idx_out) {
+            mg.idx_out[qi] = (int)(uint32_t)(key & 0xFFFFFFFFull);   // NNS_KEY_NONE -> 0, as V0
+            if (mg.dist_out) mg.dist_out[qi] = __uint_as_float((uint32_t)(key >> 32));
+        }
+    };
+    if (mg.splits <= 1) {
+        for (int ql = threadIdx.x; ql < QW; ql += nthreads)
+            if (blockIdx.x * QW + ql < m) put(blockIdx.x * QW + ql, s_fkey[ql]);
+        return;
+    }
+    for (int ql = threadIdx.x; ql < QW; ql += nthreads)
+        if (blockIdx.x * QW + ql < m) {
+            const nns_key old = __hip_atomic_fetch_min(&mg.acc[blockIdx.x * QW + ql], s_fkey[ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(old));   // returning atomic: waiting for its value = it has been performed
+        }
+    __syncthreads();                   // every atomic of the workgroup is done before the arrival is counted
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(&mg.cnt[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == mg.splits - 1;
+    }
+    __syncthreads();
+    K1A_STAMP(10);
+    if (!s_last) return;               // (workgroup-uniform)
+    for (int ql = threadIdx.x; ql < QW; ql += nthreads)
+        if (blockIdx.x * QW + ql < m) {
+            const int qi = blockIdx.x * QW + ql;
+            const nns_key v = __hip_atomic_exchange(&mg.acc[qi], (nns_key)NNS_KEY_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            put(qi, v);
+        }
+    if (threadIdx.x == 0) __hip_atomic_store(&mg.cnt[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    K1A_STAMP(11);
 }
 
 // ---------------------------------------------------------------------------

@@ -309,7 +309,8 @@ struct OpBF16T {
             asm volatile("s_nop 7");
             asm volatile("" : "+v"(c.template at<1, 0>()), "+v"(c.template at<1, 1>()), "+v"(c.template at<1, 2>()), "+v"(c.template at<1, 3>()));
             asm volatile("" : "+v"(c.template at<1, 4>()), "+v"(c.template at<1, 5>()), "+v"(c.template at<1, 6>()), "+v"(c.template at<1, 7>()));
-        } else if constexpr (ASM_) asm volatile("s_nop 7" : "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13));
+        } else if constexpr (ASM_ && QB_ == 1) asm volatile("s_nop 7" : "+v"(c.t10), "+v"(c.t11));   // (two query tiles per wave)
+        else if constexpr (ASM_) asm volatile("s_nop 7" : "+v"(c.t10), "+v"(c.t11), "+v"(c.t12), "+v"(c.t13));
         // (builtin MFMAs: hipcc's hazard recognizer places the wait states)
     }
 };
@@ -319,7 +320,15 @@ using OpBF16K128 = OpBF16T<8>;    // KT = 128: k <= 128 without padding to 256 (
 // registers, so four waves per workgroup (one per SIMD) = 256 queries; a 1 KiB LDS fragment still feeds FOUR
 // MFMAs (the 32x32x16 form of OpBF16K512: one — LDS-bandwidth bound at 55 % of peak).  Compiler builtins
 // instead of inline asm: an asm "v" operand must sit in the 256 architectural VGPRs.
+#ifndef NNS_K512_NW4
+// Round 3: EIGHT waves x 32 queries (two query tiles per wave, 128 operand registers): the same 256 queries per
+// workgroup, but two waves per SIMD — a partner issues MFMAs while a wave sits in an LDS-DMA issue — and in-place asm
+// MFMAs (the four-wave form's operands spill into AGPRs and hipcc copies one back per MFMA: 70 v_accvgpr_read per 64
+// MFMAs).  A 1 KiB fragment feeds two MFMAs per wave: LDS fragment reads 32 of every 64 cycles.
+using OpBF16K512T = OpBF16T<32, 8, true, 1>;
+#else
 using OpBF16K512T = OpBF16T<32, 4, false>;
+#endif
 // KT = 256 with 128 queries per wave on four waves (experiment, -DNNS_BF16_WIDE): half the LDS fragment reads per MFMA
 using OpBF16Wide = OpBF16T<16, 4, true, 4>;
 
@@ -904,13 +913,16 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         if constexpr (T16) {
             constexpr int b = decltype(b_c)::value;
             constexpr int NKS = SPB / 2;              // k-steps of 32 dims per 16-ref tile
-            static_assert(NKS >= 3, "the other tile is retired at k-steps 1 and 2");
+            // (with two query tiles per wave a step is two MFMAs: retire one k-step later, so that the reads of the other
+            //  tile's accumulators still sit >= 5 MFMAs behind the MFMAs that finished them)
+            constexpr int RET = NT16 >= 4 ? 1 : 2;
+            static_assert(NKS >= RET + 2, "the other tile is retired at k-steps RET and RET + 1");
             constexpr int rt = b / NKS, ks = b % NKS, ot = 1 - rt;
             static_for<NT16>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int qt = decltype(qc)::value;
                 if constexpr (ks == 0) OP::mma16_seed(frag, bq[qt][0], acc.template at<rt, qt>(), rt == 0 ? nseed0 : nseed1);
                 else OP::mma16(frag, bq[qt][ks], acc.template at<rt, qt>());
-                if constexpr (ks == 1) {
+                if constexpr (ks == RET) {
                     // Name the retiring tile's accumulator as ONE in/out tuple before its elements are read:
                     // without it hipcc carries elements 1 and 3 of each tile across the loop back-edge in
                     // separate registers (8 v_mov at the latch, 8 more to put them back in front of the tile's
@@ -923,8 +935,8 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                     __builtin_amdgcn_sched_barrier(0);   // keep the pair right behind its MFMA
                 }
             });
-            if constexpr (ks == 1 && (kAblate & 2) == 0) t16_masks();
-            if constexpr (ks == 2 && (kAblate & 2) == 0) t16_test(acc, rt == 0 ? blk_global - 1 : blk_global, std::integral_constant<int, ot>{});
+            if constexpr (ks == RET && (kAblate & 2) == 0) t16_masks();
+            if constexpr (ks == RET + 1 && (kAblate & 2) == 0) t16_test(acc, rt == 0 ? blk_global - 1 : blk_global, std::integral_constant<int, ot>{});
         }
     };
 

@@ -1739,3 +1739,47 @@ def test_k1c_streaming_kernel_few_queries(pkg, orc):
     torch.cuda.synchronize()
     assert np.array_equal(got.cpu().numpy(), want_idx)
     ix.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_k1f_low_dim_filter_and_rerank_paths(pkg, orc, k):
+    """K1f (exact_kernels.hip): k <= 3 above 2^24 pairs runs as a VALU FMA filter + V0 re-rank of the best two 16-ref
+    chunks.  Every exit of it against the oracle: the plain case, near-ties that put the answer in the SECOND chunk,
+    three chunks within tau (the workgroup scans the range for that query), so many of those that the workgroup walks
+    its range exactly, NaN / INF / huge refs (the same walk), clouds far from the origin, lattices, ragged sizes."""
+    rng = np.random.default_rng(900 + k)
+    m, n = 2048 + 37, 16384 + 13        # > 2^24 pairs, ranges of >= 512 refs, both sizes ragged
+    q = rng.random((m, k), dtype=np.float32)
+    r = rng.random((n, k), dtype=np.float32)
+    _check(pkg, orc, q, r, paths=("auto", "exact"), shards=(1, 3))
+    # a cloud far from the origin (the centred scores keep their resolution)
+    _check(pkg, orc, q + np.float32(4096.0), r + np.float32(4096.0), paths=("exact",))
+    # every ref four times, 4099 refs apart: ties across chunks, waves and ranges (the lowest index wins), and more
+    # than two chunks within tau for EVERY query
+    base = rng.random((4099, k), dtype=np.float32)
+    r4 = np.concatenate([base, base, base, base])[:n]
+    _check(pkg, orc, q, r4, paths=("exact",), shards=(1, 2))
+    # a few planted near-duplicates: for some queries three chunks hold a ref within tau of the best
+    r5 = r.copy()
+    for t in range(40):
+        src = int(rng.integers(0, n))
+        for d in (1, 2, 3):
+            r5[(src + 1777 * d) % n] = r5[src] + np.float32(1e-7) * d
+    q5 = q.copy()
+    q5[:40] = r5[rng.integers(0, n, 40)] + np.float32(1e-3)
+    _check(pkg, orc, q5, r5, paths=("exact",))
+    # integer lattice: exact ties everywhere
+    rl = rng.integers(0, 24, (n, k)).astype(np.float32)
+    ql = rng.integers(0, 24, (m, k)).astype(np.float32) + np.float32(0.5)
+    _check(pkg, orc, ql, rl, paths=("exact",))
+    # non-finite and huge refs (a workgroup that sees one walks its range with V0's arithmetic), non-finite queries
+    r6 = r.copy()
+    r6[5, 0] = np.nan
+    r6[700, k - 1] = np.inf
+    r6[9000, 0] = np.float32(3e18)
+    r6[12000, 0] = np.float32(-1e30)
+    q6 = q.copy()
+    q6[3, 0] = np.nan
+    q6[4, k - 1] = np.inf
+    q6[5, 0] = np.float32(2e19)
+    _check(pkg, orc, q6, r6, paths=("exact",), shards=(1, 2))

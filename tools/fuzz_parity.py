@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max-pairs", type=float, default=3e8)
+    ap.add_argument("--lowdim", action="store_true", help="only shapes of K1f's domain: k <= 3, >= 2^24 pairs, fp32")
     a = ap.parse_args()
     pkg, orc = graft.load_package(), graft.load_oracle()
     rng = np.random.default_rng(a.seed)
@@ -70,8 +71,12 @@ def main():
         if rng.integers(0, 40) == 0:
             k, m, n = [(3, 4096, 700000), (16, 4096, 600000), (128, 4096, 70000)][int(rng.integers(0, 3))]
             n += int(rng.integers(0, 1000))
+        if a.lowdim:
+            k = int(rng.choice([1, 2, 3, 3]))
+            m = int(rng.choice([300, 513, 1000, 2049, 4096, 5000]))
+            n = int(rng.choice([9000, 20001, 70000, 150000, 400000])) + int(rng.integers(0, 40))
         fam = str(rng.choice(families))
-        bf16 = bool(rng.integers(0, 3) == 0) and fam not in ("huge",)
+        bf16 = bool(rng.integers(0, 3) == 0) and fam not in ("huge",) and not a.lowdim
         # ("mfma_perref": the long-stream record form of the filter forced at any size, NNS_RECORDS_PER_REF)
         path = str(rng.choice(["auto", "auto", "mfma", "mfma_perref", "exact"]))
         if path.startswith("mfma") and k > (1024 if bf16 else 256):
