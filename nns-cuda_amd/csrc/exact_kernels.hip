@@ -690,6 +690,12 @@ static int launch_k1a(int m, int n, const float *q, const float *r, int64_t base
 //     than a few queries need it, or a ref is NaN / INF / huge (a score could overflow), every lane walks the range for
 //     its own queries exactly as K1a does.  Slower on such inputs, never different.
 // The cross-split stage is K1a's (returning atomic mins on exact keys, last workgroup writes), minus the index recovery.
+// Measured (profiles/r03_ab_k1f.txt, r03_k1f_timeline.txt): C2 49.6 -> 40.3 us.  The walk is 5.2 instructions per pair
+// (3 FMAs, 0.5 v_min3, the insert, one broadcast ds_read_b128 + its wait per ref and wave) and runs at the LDS's pace:
+// with half the reads (diagnostic build) the launch takes 34 us.  Tried and slower: four queries per lane (fewer reads
+// per pair, 121-137 registers: one or two workgroups per CU), 32-ref chunks, 64 registers with four workgroups per CU,
+// and refs handed to the lanes by v_readlane from one lane-linear read (4 scalar moves per ref cost 4 / (3 QPL) of the
+// FMAs' issue slots).
 #ifndef NNS_K1F_MAX_AMB
 #define NNS_K1F_MAX_AMB 8       // ambiguous queries a workgroup scans one by one before it falls back as a whole
 #endif
@@ -842,24 +848,41 @@ __global__ __launch_bounds__(512) void lowdim_filter_kernel(
             float tmq[QPL];
 #pragma unroll
             for (int u = 0; u < QPL; ++u) tmq[u] = __builtin_inff();
-#pragma unroll(CH <= 16 ? 2 : 1)
-            for (int piece = 0; piece < CH / 8; ++piece) {
-                float4 rf[8];
+#ifndef NNS_K1F_PS
+#define NNS_K1F_PS 8      // refs per piece
+#endif
+#ifndef NNS_K1F_UNROLL
+#define NNS_K1F_UNROLL (CH <= 16 && NNS_K1F_PS == 8 ? 2 : 1)
+#endif
+            constexpr int PS = NNS_K1F_PS;
+            static_assert(PS == 4 || PS == 8, "a piece is 4 or 8 refs");
+            constexpr int UNR = NNS_K1F_UNROLL;
+#pragma unroll(UNR)
+            for (int piece = 0; piece < CH / PS; ++piece) {
+                float4 rf[PS];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) rf[e] = tile[c + 8 * piece + e];   // uniform address: broadcast reads
+#if defined(NNS_DIAG) && defined(NNS_K1F_HALFREADS)   // timing experiment: half the LDS reads, the same arithmetic (results are wrong)
+                for (int e = 0; e < PS; ++e) rf[e] = tile[c + PS * piece + (e & 3)];
+#else
+                for (int e = 0; e < PS; ++e) rf[e] = tile[c + PS * piece + e];   // uniform address: broadcast reads
+#endif
 #pragma unroll
                 for (int u = 0; u < QPL; ++u) {
-                    float sc[8];
+                    float sc[PS];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
+                    for (int e = 0; e < PS; ++e) {
                         float a = rf[e].w;
                         a = __builtin_fmaf(x2[u][0], rf[e].x, a);
                         if constexpr (K > 1) a = __builtin_fmaf(x2[u][1], rf[e].y, a);
                         if constexpr (K > 2) a = __builtin_fmaf(x2[u][2], rf[e].z, a);
                         sc[e] = a;
                     }
-                    const float g0 = fminf(fminf(sc[0], sc[1]), sc[2]), g1 = fminf(fminf(sc[3], sc[4]), sc[5]);
-                    tmq[u] = fminf(fminf(fminf(g0, g1), fminf(sc[6], sc[7])), tmq[u]);
+                    if constexpr (PS == 8) {
+                        const float g0 = fminf(fminf(sc[0], sc[1]), sc[2]), g1 = fminf(fminf(sc[3], sc[4]), sc[5]);
+                        tmq[u] = fminf(fminf(fminf(g0, g1), fminf(sc[6], sc[7])), tmq[u]);
+                    } else {
+                        tmq[u] = fminf(fminf(fminf(sc[0], sc[1]), sc[2]), fminf(sc[3], tmq[u]));
+                    }
                 }
             }
 #pragma unroll
