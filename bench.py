@@ -406,10 +406,10 @@ def run_workload(ctx, name, steps, warmup, seed=1000):
         traffic, tsrc = load_traffic(f"exact_{name}")
         # V0's sub, mul, add (core.cu:41-42) must stay three roundings — nothing may fuse — so the kernel retires ONE flop
         # per lane-instruction where the 157.3 TF vector peak counts an FMA's two: the reachable ceiling is half of it
-        # (k <= 3 above 2^24 pairs — launch_k1a's rule — runs as K1f: k FMAs per pair on prepared refs + V0's own
+        # (k <= 3 from 2^27 pairs — launch_k1a's rule — runs as K1f: k FMAs per pair on prepared refs + V0's own
         #  arithmetic on the 32 refs of each query's two best chunks; the line keeps V0's 3k flop per pair as the
         #  algorithmic count and the non-FMA ceiling as the yardstick of the kernel it replaced)
-        k1f = k <= 3 and m >= 64 and m * n_local >= 2 ** 24
+        k1f = k <= 3 and m >= 64 and m * n_local >= 2 ** 27
         roof = {"bound": "valu", "kernel": "lowdim_filter_kernel (K1f: VALU FMA filter + V0 re-rank)" if k1f else "exact_lane_query_kernel",
                 "achieved": achieved,
                 "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_VALU_TFLOPS,

@@ -562,7 +562,9 @@ template <int K>
 __global__ void lowdim_filter_kernel(int m, int n, int refs_per_split, const float *__restrict__ q, const float *__restrict__ r,
                                      int64_t index_base, nns_key *__restrict__ keys, const K1aMerge mg);
 #ifndef NNS_K1F_MIN_PAIRS
-#define NNS_K1F_MIN_PAIRS ((int64_t)1 << 24)
+// K1f against K1a by size (tools/probe_k1f_crossover.py, profiles/r03_k1f_crossover.txt): 2^26 pairs 19.8 vs 18.4 us and
+// 17.8 vs 15.4 (its fixed 18 us of staging, merges and re-rank), 2^27 26.1 vs 26.8, 2^28 36.3 vs 43.1, 2^30 121 vs 153
+#define NNS_K1F_MIN_PAIRS ((int64_t)1 << 27)
 #endif
 #ifndef NNS_K1F_MIN_PER
 #define NNS_K1F_MIN_PER 512

@@ -1743,22 +1743,22 @@ def test_k1c_streaming_kernel_few_queries(pkg, orc):
 
 @pytest.mark.parametrize("k", [1, 2, 3])
 def test_k1f_low_dim_filter_and_rerank_paths(pkg, orc, k):
-    """K1f (exact_kernels.hip): k <= 3 above 2^24 pairs runs as a VALU FMA filter + V0 re-rank of the best two 16-ref
+    """K1f (exact_kernels.hip): k <= 3 from 2^27 pairs runs as a VALU FMA filter + V0 re-rank of the best two 16-ref
     chunks.  Every exit of it against the oracle: the plain case, near-ties that put the answer in the SECOND chunk,
     three chunks within tau (the workgroup scans the range for that query), so many of those that the workgroup walks
     its range exactly, NaN / INF / huge refs (the same walk), clouds far from the origin, lattices, ragged sizes."""
     rng = np.random.default_rng(900 + k)
-    m, n = 2048 + 37, 16384 + 13        # > 2^24 pairs, ranges of >= 512 refs, both sizes ragged
+    m, n = 2048 + 37, 65536 + 13        # > 2^27 pairs, ranges of >= 512 refs, both sizes ragged (two shards: K1a)
     q = rng.random((m, k), dtype=np.float32)
     r = rng.random((n, k), dtype=np.float32)
-    _check(pkg, orc, q, r, paths=("auto", "exact"), shards=(1, 3))
+    _check(pkg, orc, q, r, paths=("auto", "exact"), shards=(1, 2))
     # a cloud far from the origin (the centred scores keep their resolution)
     _check(pkg, orc, q + np.float32(4096.0), r + np.float32(4096.0), paths=("exact",))
-    # every ref four times, 4099 refs apart: ties across chunks, waves and ranges (the lowest index wins), and more
+    # every ref four times, 16411 refs apart: ties across chunks, waves and ranges (the lowest index wins), and more
     # than two chunks within tau for EVERY query
-    base = rng.random((4099, k), dtype=np.float32)
+    base = rng.random((16411, k), dtype=np.float32)
     r4 = np.concatenate([base, base, base, base])[:n]
-    _check(pkg, orc, q, r4, paths=("exact",), shards=(1, 2))
+    _check(pkg, orc, q, r4, paths=("exact",))
     # a few planted near-duplicates: for some queries three chunks hold a ref within tau of the best
     r5 = r.copy()
     for t in range(40):
@@ -1782,4 +1782,4 @@ def test_k1f_low_dim_filter_and_rerank_paths(pkg, orc, k):
     q6[3, 0] = np.nan
     q6[4, k - 1] = np.inf
     q6[5, 0] = np.float32(2e19)
-    _check(pkg, orc, q6, r6, paths=("exact",), shards=(1, 2))
+    _check(pkg, orc, q6, r6, paths=("exact",))

@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max-pairs", type=float, default=3e8)
-    ap.add_argument("--lowdim", action="store_true", help="only shapes of K1f's domain: k <= 3, >= 2^24 pairs, fp32")
+    ap.add_argument("--lowdim", action="store_true", help="only shapes of K1f's domain: k <= 3, mostly >= 2^27 pairs, fp32")
     a = ap.parse_args()
     pkg, orc = graft.load_package(), graft.load_oracle()
     rng = np.random.default_rng(a.seed)
@@ -73,8 +73,8 @@ def main():
             n += int(rng.integers(0, 1000))
         if a.lowdim:
             k = int(rng.choice([1, 2, 3, 3]))
-            m = int(rng.choice([300, 513, 1000, 2049, 4096, 5000]))
-            n = int(rng.choice([9000, 20001, 70000, 150000, 400000])) + int(rng.integers(0, 40))
+            m = int(rng.choice([513, 1000, 2049, 4096, 5000]))
+            n = int(rng.choice([30000, 70000, 150000, 400000])) + int(rng.integers(0, 40))
         fam = str(rng.choice(families))
         bf16 = bool(rng.integers(0, 3) == 0) and fam not in ("huge",) and not a.lowdim
         # ("mfma_perref": the long-stream record form of the filter forced at any size, NNS_RECORDS_PER_REF)
