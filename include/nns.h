@@ -267,6 +267,13 @@ int nns_selftest_mfma(int kt, int bf16, const float *a, const float *b, const fl
  * share thresholds, records per ref tile} (the short-stream forms).  NNS_ERR_UNSUPPORTED beyond the deepest
  * tile.  Lets CPU tests check the planner's invariants (coverage, padding, whole blocks per split). */
 int nns_plan_filter(int k, int m, int n, int bf16_points, unsigned flags, int *out, int out_len);
+/* Diagnostic (host only, no device needed): the launch geometry of the EXACT path (the reference's V1-V7 kernels,
+ * core.cu:58-696) for a k-D search of m queries over n refs.  out[0..5] = {kernel: 0 K1a (lane = query, exact), 1 K1f
+ * (k <= 3 from 2^27 pairs: vector-ALU filter + V0 re-rank in the same launch), 2 K1b (lane = ref), 3 K1c (<= 4 queries:
+ * the HBM-streaming form); query tiles (grid.x); ref ranges (grid.y, 0 = chosen at launch); refs per range; waves per
+ * workgroup; queries per workgroup}.  refs_aligned: the refs are 16-byte aligned; have_workspace: the merge workspace
+ * exists (without it K1a / K1f run one ref range per query tile).  Lets CPU tests check the planner's invariants. */
+int nns_plan_exact(int k, int m, int n, int refs_aligned, int have_workspace, int *out, int out_len);
 /* Diagnostic: what the filter's slow path does when the lanes that carry one query share their record
  * thresholds (short ref streams): out64[l] = min of in64 over the lanes l ^ 32 (tile16 = 0: 32x32 MFMA tiles)
  * or l ^ 16, l ^ 32, l ^ 48 (tile16 = 1: 16x16 tiles) — through the very row-swap instructions the kernel

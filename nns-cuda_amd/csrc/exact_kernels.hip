@@ -859,7 +859,7 @@ __global__ __launch_bounds__(512) void lowdim_filter_kernel(
             constexpr int PS = NNS_K1F_PS;
             static_assert(PS == 4 || PS == 8, "a piece is 4 or 8 refs");
             constexpr int UNR = NNS_K1F_UNROLL;
-#pragma unroll(UNR)
+#pragma unroll UNR
             for (int piece = 0; piece < CH / PS; ++piece) {
                 float4 rf[PS];
 #pragma unroll
@@ -1799,6 +1799,80 @@ size_t exact_workspace_keys(int k, int m, int n)
     case 8: return k1a_workspace_keys<8>(m, n);
     default: return k1a_workspace_keys<16>(m, n);
     }
+}
+
+// the geometry launch_exact_search would use (host only; nns_plan_exact): v[0] = kernel (0 K1a, 1 K1f, 2 K1b, 3 K1c),
+// v[1] = query tiles (grid.x), v[2] = ref ranges (grid.y), v[3] = refs per range, v[4] = waves per workgroup,
+// v[5] = queries per workgroup.  `aligned`: the refs are 16-byte aligned (K1c's condition); `have_ws`: the merge
+// workspace could be allocated.
+template <int K>
+static void exact_plan_k1a(int m, int n, bool have_ws, int *v)
+{
+    K1aPlan p = k1a_plan<K>(m, n);
+    v[0] = 0;
+    v[5] = 64 * K1A_QPL;
+    if (p.splits > 1 && !have_ws) {
+        p.splits = 1;
+        p.per = divup(n, K1aChunk<K>::value) * K1aChunk<K>::value;
+    }
+    if constexpr (K <= 3) {
+        if (k1f_wanted<K>(m, n, p)) {   // (the same re-cut as launch_k1a)
+            const int qtf = divup(m, 64 * K1F_QPL);
+            int want = divup(NNS_K1F_WAVES, qtf * 8);
+            const int maxs = divup(n, NNS_K1F_MIN_PER);
+            if (want > maxs) want = maxs;
+            if (want < 1) want = 1;
+            const int per = divup(divup(n, want), K1F_CH) * K1F_CH;
+            const int splits = divup(n, per);
+            if (splits <= 1 || (have_ws && p.splits > 1)) {
+                v[0] = 1;
+                v[5] = 64 * K1F_QPL;
+                p.qtiles = qtf;
+                p.splits = splits;
+                p.per = per;
+                p.nw = 8;
+            }
+        }
+    }
+    v[1] = p.qtiles;
+    v[2] = p.splits;
+    v[3] = p.per;
+    v[4] = p.nw;
+}
+
+int exact_plan(int k, int m, int n, bool aligned, bool have_ws, int *v)
+{
+    if (m >= 64 && k1a_dim(k)) {
+        switch (k) {
+        case 1: exact_plan_k1a<1>(m, n, have_ws, v); break;
+        case 2: exact_plan_k1a<2>(m, n, have_ws, v); break;
+        case 3: exact_plan_k1a<3>(m, n, have_ws, v); break;
+        case 4: exact_plan_k1a<4>(m, n, have_ws, v); break;
+        case 8: exact_plan_k1a<8>(m, n, have_ws, v); break;
+        default: exact_plan_k1a<16>(m, n, have_ws, v); break;
+        }
+        return NNS_OK;
+    }
+    if (m <= kStreamMaxQ && have_ws && (k <= 3 || (aligned && (k == 4 || k == 8 || k == 16 || k == 32)))) {
+        v[0] = 3;
+        v[1] = 1;
+        v[2] = k1c_workgroups(k, n);
+        v[3] = divup(n, v[2]);
+        v[4] = 8;
+        v[5] = m;
+        return NNS_OK;
+    }
+    NNS_TRY(check_k(k));
+    const int qt = pick_qt(k, m);
+    int groups = divup(m, qt);
+    if (groups > 4096) groups = 4096;
+    v[0] = 2;
+    v[1] = groups;
+    v[2] = 0;   // (K1b's grid over the refs is chosen at launch)
+    v[3] = n;
+    v[4] = 4;
+    v[5] = qt;
+    return NNS_OK;
 }
 
 int launch_exact_search(int k, int m, int n, const float *q, const float *r,

@@ -751,6 +751,16 @@ int nns_plan_filter(int k, int m, int n, int bf16_points, unsigned flags, int *o
     return NNS_OK;
 }
 
+int nns_plan_exact(int k, int m, int n, int refs_aligned, int have_workspace, int *out, int out_len)
+{
+    if (!out || out_len < 6 || k <= 0 || m <= 0 || n <= 0) return NNS_ERR_INVALID;
+    if ((int64_t)m > kMaxPoints || (int64_t)n > kMaxPoints) return NNS_ERR_INVALID;
+    int v[6] = {0, 0, 0, 0, 0, 0};
+    NNS_TRY(exact_plan(k, m, n, refs_aligned != 0, have_workspace != 0, v));
+    memcpy(out, v, sizeof(v));
+    return NNS_OK;
+}
+
 int nns_selftest_lane_share(int tile16, const float *in64, float *out64)
 {
     if (!in64 || !out64) return NNS_ERR_INVALID;

@@ -265,6 +265,8 @@ int launch_fill_uniform(float *dev, size_t count, uint64_t seed, uint64_t offset
 // (re)allocated since the last launch (its arrival counters are then zeroed once; they re-arm themselves).
 // idx_out / dist_out (optional): also write the unpacked indices / distances (K1a: same launch).
 size_t exact_workspace_keys(int k, int m, int n);
+// the exact path's launch geometry for a shape (host only: nns_plan_exact)
+int exact_plan(int k, int m, int n, bool aligned, bool have_ws, int *v6);
 int launch_exact_search(int k, int m, int n, const float *q, const float *r,
                         int64_t index_base, nns_key *keys, nns_key *ws, size_t ws_keys, bool ws_fresh,
                         int *idx_out, float *dist_out, hipStream_t st);

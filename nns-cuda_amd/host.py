@@ -44,7 +44,7 @@ ABI_SYMBOLS = (
     "nns_last_error", "nns_version", "nns_selftest_mfma",
     "nns_index_create_bf16", "nns_index_search_bf16", "nns_search_bf16_ex", "nns_search_f32_multi",
     "nns_trim", "nns_warmup", "nns_shutdown", "nns_search_bf16_multi",
-    "nns_index_near_ties", "nns_tau_consts", "nns_index_search_indices", "nns_selftest_lane_share", "nns_plan_filter",
+    "nns_index_near_ties", "nns_tau_consts", "nns_index_search_indices", "nns_selftest_lane_share", "nns_plan_filter", "nns_plan_exact",
     "nns_comm_unique_id", "nns_comm_create", "nns_comm_size", "nns_comm_allreduce_min", "nns_comm_destroy",
     "nns_multi_last_exchange_ranks",
 )
@@ -111,6 +111,7 @@ def _load() -> ctypes.CDLL:
     lib.nns_tau_consts.argtypes = [c_int, ctypes.c_float, ctypes.c_float, c_int, c_vp]
     lib.nns_selftest_lane_share.argtypes = [c_int, c_vp, c_vp]
     lib.nns_plan_filter.argtypes = [c_int, c_int, c_int, c_int, c_u, c_vp, c_int]
+    lib.nns_plan_exact.argtypes = [c_int, c_int, c_int, c_int, c_int, c_vp, c_int]
     lib.nns_keys_min.argtypes = [c_vp, c_vp, c_int, c_vp]
     lib.nns_keys_unpack.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp]
     lib.nns_fill_uniform.argtypes = [c_vp, c_sz, c_u64, c_u64, c_vp]
@@ -160,6 +161,16 @@ def plan_filter(k: int, m: int, n: int, bf16: bool = False, flags: int = 0) -> d
     names = ("kt", "bf16", "mixed", "lpq", "m_pad", "n_pad", "total_slots", "splits", "slots_per_split", "qgroups",
              "slot_pts", "queries_per_wg", "share_thr", "tile_rec")
     return dict(zip(names, (int(v) for v in out)))
+
+
+def plan_exact(k: int, m: int, n: int, refs_aligned: bool = True, have_workspace: bool = True) -> dict:
+    """nns_plan_exact: the exact path's launch geometry for a shape (host only)."""
+    out = np.zeros(6, np.int32)
+    _check(lib.nns_plan_exact(k, m, n, int(refs_aligned), int(have_workspace), out.ctypes.data, 6), "nns_plan_exact")
+    names = ("kernel", "qtiles", "splits", "per", "waves", "queries_per_wg")
+    d = dict(zip(names, (int(v) for v in out)))
+    d["kernel"] = ("k1a", "k1f", "k1b", "k1c")[d["kernel"]]
+    return d
 
 
 def selftest_lane_share(values, tile16: bool) -> np.ndarray:

@@ -81,3 +81,36 @@ def test_plan_invariants_random_shapes(pkg):
         _check_plan(p, k, m, n)
         if p["kt"] == 1024:
             assert p["slots_per_split"] % 2 == 0 and p["total_slots"] % 2 == 0
+
+
+def test_exact_path_plans(pkg):
+    """nns_plan_exact (host only): which exact kernel a shape takes and how its grid covers the refs.  K1f (the
+    vector-ALU filter + V0 re-rank, k <= 3) starts at 2^27 pairs and needs ranges of >= 512 refs in whole 16-ref chunks;
+    the reference driver's samples (main.cu:38-51) land where DESIGN says; sizes near 2^31 do not overflow."""
+    P = pkg.plan_exact
+    # the reference driver's table
+    assert P(3, 1, 1024)["kernel"] == "k1c" and P(16, 1, 65536)["kernel"] == "k1c"
+    assert P(3, 1024, 1024)["kernel"] == "k1a" and P(3, 1024, 65536)["kernel"] == "k1a"     # 2^26 pairs: K1a
+    assert P(3, 1024, 1048576)["kernel"] == "k1f"
+    c2 = P(3, 4096, 65536)
+    assert c2["kernel"] == "k1f" and c2["waves"] == 8 and c2["queries_per_wg"] == 128
+    assert c2["qtiles"] * c2["splits"] * 8 <= 4096 and c2["per"] % 16 == 0 and c2["per"] >= 512
+    # K1f needs k <= 3, the merge workspace (or a single range) and >= 2^27 pairs
+    assert P(4, 4096, 65536)["kernel"] == "k1a" and P(8, 4096, 65536)["kernel"] == "k1a"
+    assert P(3, 4096, 65536, have_workspace=False)["kernel"] == "k1a"
+    assert P(3, 2048, 65535)["kernel"] == "k1a" and P(3, 2048, 65536)["kernel"] == "k1f"
+    assert P(5, 4096, 65536)["kernel"] == "k1b" and P(3, 63, 65536)["kernel"] == "k1b"
+    assert P(16, 4, 1048576, refs_aligned=False)["kernel"] == "k1b" and P(3, 4, 1048576, refs_aligned=False)["kernel"] == "k1c"
+    rng = np.random.default_rng(5)
+    for _ in range(3000):
+        k = int(rng.choice([1, 2, 3, 4, 8, 16]))
+        m = int(rng.integers(64, 200000)) if rng.integers(0, 4) else int(rng.integers(64, 2**31 - 2**20))
+        n = int(rng.integers(1, 3000000)) if rng.integers(0, 4) else int(rng.integers(1, 2**31 - 2**20))
+        p = P(k, m, n)
+        assert p["kernel"] in ("k1a", "k1f")
+        assert p["splits"] >= 1 and p["per"] >= 1 and p["qtiles"] * p["queries_per_wg"] >= m
+        assert p["splits"] * p["per"] >= n and (p["splits"] - 1) * p["per"] < n          # the ranges cover the refs, none is empty
+        assert p["splits"] <= 65535 and 1 <= p["waves"] <= 16
+        if p["kernel"] == "k1f":
+            assert k <= 3 and m * n >= 2**27 and p["per"] % 16 == 0 and p["waves"] == 8
+            assert p["per"] >= 512 or p["splits"] == 1
