@@ -557,7 +557,10 @@ static size_t k1a_workspace_keys(int m, int n)
 #endif
 constexpr int K1F_CH = NNS_K1F_CH;      // refs per chunk (16 or 32)
 constexpr int K1F_QPL = NNS_K1F_QPL;    // queries per lane
-constexpr int K1F_TILE = 1024;  // refs per LDS tile: 16 KiB of float4
+#ifndef NNS_K1F_TILE
+#define NNS_K1F_TILE 1024
+#endif
+constexpr int K1F_TILE = NNS_K1F_TILE;  // refs per LDS tile: 16 KiB of float4
 template <int K>
 __global__ void lowdim_filter_kernel(int m, int n, int refs_per_split, const float *__restrict__ q, const float *__restrict__ r,
                                      int64_t index_base, nns_key *__restrict__ keys, const K1aMerge mg);
