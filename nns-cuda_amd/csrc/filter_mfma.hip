@@ -458,7 +458,14 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
     // barrier that opens interval s, so they fill slot s + 3 = s - 1 (mod 4) and wait with a COUNTED vmcnt that
     // leaves the youngest slot's pieces in flight across the barrier: TWO intervals of latency cover.
     constexpr int AHEAD = (OP::kLag || F_DMA_AHEAD_MAX < 3) ? 2 : 3;
-    constexpr int F_PPS = F_PPW + F_NP;                 // DMA pieces per wave and slot
+#ifndef NNS_F_NORM_ONE
+#define NNS_F_NORM_ONE 1
+#endif
+    // DMA pieces per wave and slot that the counted vmcnt waits may leave in flight: with the norms issued by one wave
+    // per slot, a wave's youngest slot has F_PPW or F_PPW + F_NP pieces — counting F_PPW is safe for both
+    // (not the 768-deep tile: 252 of its 256 registers are taken, the turn-taking test spills)
+    constexpr bool NORM_ONE = NNS_F_NORM_ONE && SPB != 48;
+    constexpr int F_PPS = NORM_ONE ? F_PPW : F_PPW + F_NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -536,9 +543,13 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
         if (p < F_PPW) {
             const int piece = wave * F_PPW + p;
             dma16(a.rimg + gslot * F_SLOT_COORD + piece * 1024 + lane * 16, dst + piece * 1024);
+        } else if (NORM_ONE && ((int)gslot & (F_NW - 1)) != wave) {
+            // the slot's norms are ONE wave's business, the waves taking turns slot by slot (round 1 - 3: every wave copied
+            // the same bytes to the same words, to keep the DMA counts per slot identical — eight pieces where one does,
+            // and an LDS-DMA piece costs its SIMD ~130 cycles of MFMA issue whatever its size); the counted vmcnt waits
+            // below therefore count IMAGE pieces only (a wave whose youngest slot carries norm pieces waits for them too)
         } else if constexpr (SLOT_REFS <= 64) {   // (128- and 256-ref slots: one dwordx4 piece of 256 norms)
-            // the slot's norms: every wave copies the same bytes to the same words (keeps each
-            // wave's DMA count per slot identical; a 32-ref slot also copies the next slot's 32)
+            // (a 32-ref slot also copies the next slot's 32)
             dma4(a.rnorm + (gslot / SPBLK) * SLOT_REFS + lane, dst + F_SLOT_COORD);   // (a deep block: both its slots)
         } else {
             const int np = p - F_PPW;             // 256 norms per piece (a deep block: its super-period's, + over-read)
