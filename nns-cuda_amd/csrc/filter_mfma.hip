@@ -196,6 +196,9 @@ template <int SPB, int QB_>
 struct OpF32T {  // fp32 operands: float4 #b = operands of MFMA k-steps 4b .. 4b+3 (8 dims per fragment)
     static constexpr int kSPB = SPB;          // fragment steps per 32-point image block: KT = 8 * SPB
     static constexpr bool kTile16 = false;    // 32x32 MFMA tiles: a lane owns one query per query block
+    // a slot's ring DMA pieces back to back (see the interval) — where it measured faster: KT = 128 (+0.65 % on long streams:
+    // C3) and KT = 32 (+0.8 %); KT = 16 / 64 / 256 within -0.4 .. +0.1 %: one piece per step as before
+    static constexpr bool kDmaBurst = SPB == 16 || SPB == 4;
     // SIMD partners half a block out of phase (+1.3 % on C3); a 2-step block (KT = 16) has no half to lag by
     static constexpr bool kLag = SPB >= 4;
     // the lanes' tau constants (c0, x2 per state) stay in registers: an LDS round trip on the slow path
@@ -249,6 +252,7 @@ struct OpBF16T {
     static constexpr int kSPB = SPB_;         // 16: KT = 256 (8 k-steps per 16-ref tile); 8: KT = 128 (4 k-steps); 32: KT = 512
     static constexpr bool kAsmMfma = ASM_;    // false: compiler builtins (the 512-deep form: operands beyond the 256 ArchVGPRs an asm "v" can name)
     static constexpr bool kTile16 = true;
+    static constexpr bool kDmaBurst = false;
     static constexpr bool kLag = false;       // lock-step SIMD partners (lagging them: +1..4 % time on C5)
     static constexpr bool kTauInRegs = false; // 222-234 VGPRs: the four states' constants live in LDS (read on the slow path)
     using Acc = std::conditional_t<QB_ == 4, AccSet16W, AccSet16>;
@@ -339,6 +343,7 @@ template <int SPB_, int QB_, int NW_ = NNS_F_NW_BF16, bool LAG_ = (NW_ == 8)>
 struct OpBF16T32T {
     static constexpr int kSPB = SPB_;         // fragment steps (16 dims each) per 32-ref block
     static constexpr bool kTile16 = false;
+    static constexpr bool kDmaBurst = false;
     static constexpr bool kLag = LAG_;        // (one wave per SIMD has no partner to stagger against)
     static constexpr bool kTauInRegs = true;
     using Acc = AccSet;
@@ -1025,12 +1030,20 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
                 constexpr int sp = (F_PPW + F_NP) * 2 <= 14 ? 2 : 1;   // steps between pieces
 #endif
                 static_assert(d0 + sp * (F_PPW + F_NP) <= 32, "DMA pieces must fit the interval");
+                // fp32 operators issue a slot's pieces BACK TO BACK at one step (round 3, second session): a lone LDS-DMA piece
+                // costs its SIMD ~130 cycles of MFMA issue, a burst of them far less per piece (tools/ubench/chain_loop.hip:
+                // 36.8 -> 25.2 ms); C3 118.3 -> 117.6 ms (OP::kDmaBurst: by tile depth).  The bf16 operators keep one piece per step: bursts cost THEM 1 - 6 %
+                // (profiles/r03_ab_dma_burst.txt) — their intervals are 8 - 16x shorter and a burst stalls the lock-step partner too.
 #ifdef NNS_F_DMA_BURST
-                if constexpr (t == d0) issue(s + AHEAD);
+                constexpr bool BURST = NNS_F_DMA_BURST != 0;
 #else
-                if constexpr (t >= d0 && t < d0 + sp * (F_PPW + F_NP) && (t - d0) % sp == 0)
-                    issue_piece(s + AHEAD, (t - d0) / sp);
+                constexpr bool BURST = OP::kDmaBurst;
 #endif
+                if constexpr (BURST) {
+                    if constexpr (t == d0) issue(s + AHEAD);
+                } else if constexpr (t >= d0 && t < d0 + sp * (F_PPW + F_NP) && (t - d0) % sp == 0) {
+                    issue_piece(s + AHEAD, (t - d0) / sp);
+                }
             }
             if constexpr (T16) {
                 // norms two steps ahead: tile 1 of this block; tile 0 of the next block (next ring

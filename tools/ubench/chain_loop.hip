@@ -65,6 +65,29 @@ __device__ __forceinline__ void dma4x4(const char *g, unsigned lds_byte)   // fo
                  : "memory");
 }
 
+// a wave's PPW consecutive pieces in ONE statement: M0 set once, instruction offsets 0 / 1024 / ... (burst forms)
+template <int N>
+__device__ __forceinline__ void dma16_burst_one_m0(const void *g, unsigned lds_byte)
+{
+    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
+    unsigned keep;
+    if constexpr (N == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
+    else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"((const char *)g + 4096), "s"(lds_byte + 4096) : "memory");
+    }
+}
+
 // STEPS: fragment steps per barrier interval (16: one chunk per wave and interval; 32: two); DMA / BAR: on / off
 template <int STEPS, int DMA, int BAR, int COMPUTE = 1, int STAGE = 0>
 __global__ __launch_bounds__(512) void k(float *out, const char *stream, size_t stream_bytes, const f32x4 *src, int intervals,
@@ -120,7 +143,17 @@ __global__ __launch_bounds__(512) void k(float *out, const char *stream, size_t 
                 const f32x4 *b2 = reinterpret_cast<const f32x4 *>(smem + (((c0 + 2 * (tt / 16)) & 7) * 16384)) + lane;
                 fr[tt & 3] = b2[(tt & 15) * 64];
             }
-            if (DMA && (t & 3) == 1) {
+            if (DMA && (STAGE == 5 || STAGE == 6)) {
+                if (t == 1) {   // the wave's PPW consecutive KiB of the interval's chunks, all at once
+                    const size_t cg = (size_t)(2 * CPI * (j + 2) - 1) * 16384 + (size_t)(wave * PPW) * 1024;
+                    const char *g = stream + ((cg + (size_t)(blockIdx.x >> 3) * phase) % stream_bytes) + lane * 16;
+                    const unsigned dst = lds_base + (unsigned)((cg >> 10) & 127) * 1024;
+                    if (STAGE == 5) dma16_burst_one_m0<PPW>(g, dst);
+                    else
+#pragma unroll
+                        for (int p = 0; p < PPW; ++p) dma16(g + p * 1024, dst + p * 1024);
+                }
+            } else if (DMA && (t & 3) == 1) {
                 // piece p of the two chunks (per chunk of this interval's pair) that land two intervals ahead
                 const int p = t >> 2;                         // 0 .. PPW - 1
                 const int piece = wave * PPW + p;             // 0 .. 2 STEPS - 1 (KiB of the interval's 2 CPI chunks)
@@ -224,8 +257,8 @@ int main()
     // the streamed image: 1 GiB of random bf16 pairs (every workgroup streams the same bytes, as the filter's do)
     const size_t stream_bytes = (size_t)1 << 30;
     char *stream;
-    (void)hipMalloc(&stream, stream_bytes);
-    for (size_t off = 0; off < stream_bytes; off += hsrc.size() * 4)
+    (void)hipMalloc(&stream, stream_bytes + (1 << 20));   // (+ slack: the burst forms read a wave's 8 KiB linearly past a wrapped start)
+    for (size_t off = 0; off < stream_bytes + (1 << 20); off += hsrc.size() * 4)
         (void)hipMemcpy(stream + off, hsrc.data(), hsrc.size() * 4, hipMemcpyHostToDevice);
     run<16, 0, 0>("bare: 2 MFMAs per ds_read, 8 waves", src, stream, stream_bytes);
     run<16, 0, 1>("+ barrier per 16 steps", src, stream, stream_bytes);
@@ -238,6 +271,9 @@ int main()
     run<32, 1, 1>("32 steps + DMA, phase 4 KiB", src, stream, stream_bytes, 4096);
     run<32, 1, 1>("32 steps + DMA, phase 36 KiB", src, stream, stream_bytes, 36864);
     run<32, 1, 1>("32 steps + DMA, phase 68 KiB", src, stream, stream_bytes, 69632);
+    run<32, 1, 1, 2, 5>("MFMAs w/o ds_reads + DMA burst, ONE m0 setup", src, stream, stream_bytes, 4096);
+    run<32, 1, 1, 2, 6>("MFMAs w/o ds_reads + DMA burst, m0 per piece", src, stream, stream_bytes, 4096);
+    run<32, 1, 1, 1, 5>("32 steps + DMA burst, ONE m0 setup", src, stream, stream_bytes, 4096);
     run<32, 1, 1, 2, 2>("MFMAs w/o ds_reads + DMA saddr + voffset", src, stream, stream_bytes, 4096);
     run<32, 1, 1, 2, 3>("MFMAs w/o ds_reads + DMA buffer_load offen lds", src, stream, stream_bytes, 4096);
     run<32, 1, 1, 2, 4>("MFMAs w/o ds_reads + DMA 4 dword pieces", src, stream, stream_bytes, 4096);
