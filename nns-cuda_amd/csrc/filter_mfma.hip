@@ -1027,7 +1027,10 @@ __global__ __launch_bounds__(OP::kNW * 64) void filter_kernel(const FilterArgs a
 #ifdef NNS_F_DMA_SP
                 constexpr int sp = NNS_F_DMA_SP;
 #else
-                constexpr int sp = (F_PPW + F_NP) * 2 <= 14 ? 2 : 1;   // steps between pieces
+                // steps between pieces: two where they fit — except K4's 256-deep 16x16x32 form, whose pieces go out on consecutive
+                // steps (same-device A/B on C5: 78.2 -> 77.5 ms, +0.9 %; the 512- / 384-deep tiles lose 1 % that way, three steps
+                // apart loses everywhere: profiles/r03_ab_dma_burst.txt)
+                constexpr int sp = (T16 && SPB == 16 && QB == 2) ? 1 : ((F_PPW + F_NP) * 2 <= 14 ? 2 : 1);
 #endif
                 static_assert(d0 + sp * (F_PPW + F_NP) <= 32, "DMA pieces must fit the interval");
                 // fp32 operators issue a slot's pieces BACK TO BACK at one step (round 3, second session): a lone LDS-DMA piece
